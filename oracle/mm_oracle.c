@@ -1,0 +1,360 @@
+/*
+ * mm_oracle.c -- CPU ORACLE for the MultiMesh interpolation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under multimesh_amd/ may include, link,
+ * load or call this file.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * This is an independent plain-C restatement of the reference algorithm.  Each
+ * function cites the reference lines it follows (paths relative to
+ * /root/reference/multi_mesh/).  Floating-point expressions keep the
+ * reference's association order, because parity for the weights is judged
+ * bit-for-bit; compile with -ffp-contract=off (see oracle/Makefile).
+ *
+ * Pinning: tests/test_oracle_pinned.py compares every function below with the
+ * reference's own C translation units compiled into oracle/_ref/ (when
+ * /root/reference is present) and with the committed fixtures in
+ * tests/golden/ that were generated from that build.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef long long i64;
+
+/* ------------------------------------------------------------------ */
+/* A1: element centroid.  Follows src/centroid.c:15-23: per axis, sum  */
+/* the element's nodes in connectivity order, then divide by the node  */
+/* count (a division, not a multiply by the reciprocal).               */
+/* ------------------------------------------------------------------ */
+void mmo_centroid(i64 ndim, i64 nelem, i64 nper, const i64 *conn,
+                  const double *points, double *out)
+{
+    for (i64 e = 0; e < nelem; ++e) {
+        const i64 *row = conn + e * nper;
+        for (i64 a = 0; a < ndim; ++a) {
+            double acc = 0.;
+            for (i64 p = 0; p < nper; ++p)
+                acc = acc + points[row[p] * ndim + a];
+            out[e * ndim + a] = acc / nper;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* A7: forward trilinear map of one coordinate axis                    */
+/* (src/trilinearinterpolator.c:199-212).  Node k sits at the corner   */
+/* (R,S,T)[k] of src/trilinearinterpolator.c:8-10.  Written with named */
+/* partial results; each partial is the same rounded quantity the      */
+/* reference's single expression produces, so the result is identical. */
+/* ------------------------------------------------------------------ */
+static double hex8_map_axis(const double v[8], double r, double s, double t)
+{
+    const double hr = 0.5 * (r + 1.0);
+    const double hs = 0.5 * (s + 1.0);
+    const double ht = 0.5 * (t + 1.0);
+    const double e03 = hr * (-v[0] + v[3]);
+    const double e12 = hr * (-v[1] + v[2]);
+    const double e45 = hr * (-v[4] + v[5]);
+    const double e76 = hr * (v[6] - v[7]);
+    const double bottom_s = hs * (((-v[0] + v[1]) - e03) + e12);
+    const double top_s = hs * (((-v[4] + v[7]) - e45) + e76);
+    const double along_t = ht * (((((-v[0] + v[4]) - e03) + e45) - bottom_s) + top_s);
+    return ((v[0] + e03) + bottom_s) + along_t;
+}
+
+static const double kR[8] = {-1, -1, +1, +1, -1, +1, +1, -1};
+static const double kS[8] = {-1, +1, +1, -1, -1, -1, +1, +1};
+static const double kT[8] = {-1, -1, -1, -1, +1, +1, +1, +1};
+
+/* Jacobian J[q][j] = sum_i dN_i/dxi_q * x_i[j] and its inverse via cofactors
+ * (src/trilinearinterpolator.c:214-257, :320-341, :344-359). */
+static void hex8_inverse_jacobian(const double xi[3], const double vtx[8][3],
+                                  double inv[3][3])
+{
+    double dn[3][8];
+    for (int n = 0; n < 8; ++n) {
+        dn[0][n] = 0.125 * kR[n] * (xi[1] * kS[n] + 1) * (xi[2] * kT[n] + 1);
+        dn[1][n] = 0.125 * kS[n] * (xi[0] * kR[n] + 1) * (xi[2] * kT[n] + 1);
+        dn[2][n] = 0.125 * kT[n] * (xi[0] * kR[n] + 1) * (xi[1] * kS[n] + 1);
+    }
+    double m[3][3];
+    for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int i = 0; i < 8; ++i)
+                acc = acc + dn[q][i] * vtx[i][j];
+            m[q][j] = acc;
+        }
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) -
+                       m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    const double rdet = 1 / det;
+    inv[0][0] = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * rdet;
+    inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * rdet;
+    inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * rdet;
+    inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * rdet;
+    inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * rdet;
+    inv[1][2] = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * rdet;
+    inv[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * rdet;
+    inv[2][1] = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * rdet;
+    inv[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * rdet;
+}
+
+/* ------------------------------------------------------------------ */
+/* A6: Newton inversion (src/trilinearinterpolator.c:260-305).         */
+/* xi0 = 0; tol = 1e-8 * max|v1-v0| over the axes; at most 50 steps;   */
+/* the convergence test looks at residual x, y and x again -- z is     */
+/* never tested (:290-291), and that quirk is kept on purpose.  The    */
+/* update is xi += (J^-1)^T * residual (:295-300).                     */
+/* Returns 1 when converged, 0 otherwise; *iters = residual tests done.*/
+/* ------------------------------------------------------------------ */
+int mmo_hex8_newton(const double pnt[3], const double vtx[8][3], double xi[3],
+                    int *iters)
+{
+    xi[0] = xi[1] = xi[2] = 0;
+    const double sx = fabs(vtx[1][0] - vtx[0][0]);
+    const double sy = fabs(vtx[1][1] - vtx[0][1]);
+    const double sz = fabs(vtx[1][2] - vtx[0][2]);
+    const double sxy = sx > sy ? sx : sy;
+    const double scale = sz > sxy ? sz : sxy;
+    const double tol = 1e-8 * scale;
+    double col[8];
+    for (int it = 0; it < 50; ++it) {
+        double res[3];
+        for (int a = 0; a < 3; ++a) {
+            for (int n = 0; n < 8; ++n) col[n] = vtx[n][a];
+            res[a] = pnt[a] - hex8_map_axis(col, xi[0], xi[1], xi[2]);
+        }
+        if (fabs(res[0]) < tol && fabs(res[1]) < tol && fabs(res[0]) < tol) {
+            if (iters) *iters = it + 1;
+            return 1;
+        }
+        double inv[3][3];
+        hex8_inverse_jacobian(xi, vtx, inv);
+        for (int a = 0; a < 3; ++a) {
+            /* row a of the transposed inverse = column a of inv */
+            double acc = 0;
+            for (int j = 0; j < 3; ++j) acc = acc + inv[j][a] * res[j];
+            xi[a] = xi[a] + acc;
+        }
+    }
+    if (iters) *iters = 50;
+    return 0;
+}
+
+/* A5: hull check (src/trilinearinterpolator.c:157-172): converged and every
+ * |xi| <= 2. */
+int mmo_hex8_check_hull(const double pnt[3], const double vtx[8][3], double xi[3])
+{
+    if (!mmo_hex8_newton(pnt, vtx, xi, NULL)) return 0;
+    for (int a = 0; a < 3; ++a)
+        if (fabs(xi[a]) > (1 + 1.0)) return 0;
+    return 1;
+}
+
+/* A8: the eight trilinear weights as expanded polynomials
+ * (src/trilinearinterpolator.c:174-197).  Sign table per node for the terms
+ * rst, rs, rt, r, st, s, t (the constant is always +0.125); summed strictly
+ * left to right like the reference. */
+void mmo_hex8_weights(const double xi[3], double w[8])
+{
+    static const signed char sg[8][7] = {
+        /* rst  rs  rt   r  st   s   t */
+        {-1, +1, +1, -1, +1, -1, -1},
+        {+1, -1, +1, -1, -1, +1, -1},
+        {-1, +1, -1, +1, -1, +1, -1},
+        {+1, -1, -1, +1, +1, -1, -1},
+        {+1, +1, -1, -1, -1, -1, +1},
+        {-1, -1, +1, +1, -1, -1, +1},
+        {+1, +1, +1, +1, +1, +1, +1},
+        {-1, -1, -1, -1, +1, +1, +1},
+    };
+    const double r = xi[0], s = xi[1], t = xi[2];
+    for (int n = 0; n < 8; ++n) {
+        const signed char *g = sg[n];
+        /* (+-0.125 * r * s * t) etc.: products are formed left to right and the
+         * sign rides on the exact constant 0.125, as in the reference. */
+        double acc = (g[0] * 0.125) * r * s * t;
+        acc = acc + (g[1] * 0.125) * r * s;
+        acc = acc + (g[2] * 0.125) * r * t;
+        acc = acc + (g[3] * 0.125) * r;
+        acc = acc + (g[4] * 0.125) * s * t;
+        acc = acc + (g[5] * 0.125) * s;
+        acc = acc + (g[6] * 0.125) * t;
+        acc = acc + 0.125;
+        w[n] = acc;
+    }
+}
+
+static void load_vertices(const i64 *conn, const double *nodes, i64 elem,
+                          double vtx[8][3])
+{
+    for (int n = 0; n < 8; ++n) {
+        const i64 id = conn[elem * 8 + n];
+        for (int a = 0; a < 3; ++a) vtx[n][a] = nodes[id * 3 + a];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* A4: point location + weights, src/trilinearinterpolator.c:40-148.   */
+/* Candidates are walked in the given (kNN) order.  Accept the first   */
+/* candidate whose hull check passes with max|xi| < 1.025.  Otherwise  */
+/* remember the candidate with the smallest max|xi| (strict <, first   */
+/* one wins) among those passing the hull check; after the LAST        */
+/* candidate, if that smallest value is < 1.5 re-run the hull check on */
+/* it and use it, else the point fails.  Failed rows are left          */
+/* untouched.  status (optional, our addition for tests): j of the     */
+/* accepted candidate, k + j for the fallback candidate, -1 failed.    */
+/* ------------------------------------------------------------------ */
+i64 mmo_locate_hex8(i64 k, i64 npoints, const i64 *nn, const i64 *conn,
+                    i64 *enc, const double *nodes, double *w,
+                    const double *points, int *status)
+{
+    i64 nfailed = 0;
+    for (i64 i = 0; i < npoints; ++i) {
+        const double *pnt = points + 3 * i;
+        double vtx[8][3], xi[3], wt[8];
+        double smallest = 99999999.9;
+        i64 best = -1;
+        int best_j = -1;
+        int st = -1;
+        int found = 0;
+        for (i64 j = 0; j < k; ++j) {
+            const i64 elem = nn[i * k + j];
+            load_vertices(conn, nodes, elem, vtx);
+            if (mmo_hex8_check_hull(pnt, vtx, xi)) {
+                double worst = 0.0;
+                for (int a = 0; a < 3; ++a)
+                    if (fabs(xi[a]) > worst) worst = fabs(xi[a]);
+                if (worst < (1 + 0.025)) {
+                    mmo_hex8_weights(xi, wt);
+                    for (int n = 0; n < 8; ++n) {
+                        w[i * 8 + n] = wt[n];
+                        enc[i * 8 + n] = conn[elem * 8 + n];
+                    }
+                    st = (int)j;
+                    found = 1;
+                    break;
+                } else if (worst < smallest) {
+                    smallest = worst;
+                    best = elem;
+                    best_j = (int)j;
+                }
+            }
+        }
+        if (!found) {
+            /* only reached with j == k-1 exhausted (reference :113, :138) */
+            int ok = 0;
+            if (k > 0 && smallest < 1.5 && best >= 0) {
+                load_vertices(conn, nodes, best, vtx);
+                if (mmo_hex8_check_hull(pnt, vtx, xi)) {
+                    mmo_hex8_weights(xi, wt);
+                    for (int n = 0; n < 8; ++n) {
+                        w[i * 8 + n] = wt[n];
+                        enc[i * 8 + n] = conn[best * 8 + n];
+                    }
+                    st = (int)k + best_j;
+                    ok = 1;
+                }
+            }
+            /* k == 0: the reference loop body never runs, nothing fails */
+            if (!ok && k > 0) nfailed += 1;
+        }
+        if (status) status[i] = st;
+    }
+    return nfailed;
+}
+
+/* ------------------------------------------------------------------ */
+/* A9: weighted gather, scripts/cli.py:98-100:                         */
+/*   np.sum(field[enc] * w, axis=1)                                    */
+/* Each product is rounded first; the row sum then follows NumPy's     */
+/* pairwise add-reduce for a contiguous row of P doubles (P <= 128):   */
+/* P < 8: sequential from 0; else 8 running partials r[j], folded as   */
+/* ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the P%8 tail in order.    */
+/* tests/test_oracle_pinned.py checks this against NumPy itself.       */
+/* ------------------------------------------------------------------ */
+static double numpy_row_sum(const double *a, i64 n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (i64 i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    i64 i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+/* field: [ncomp][nsrc] (one contiguous array per component, as the reference
+ * keeps one array per parameter); ids: [npoints][P]; w: [npoints][P];
+ * out: [npoints][ncomp] when out_point_major, else [ncomp][npoints]. */
+int mmo_gather(const double *field, i64 nsrc, i64 ncomp, const i64 *ids,
+               const double *w, i64 npoints, i64 P, double *out,
+               int out_point_major)
+{
+    if (P > 128) return -1;
+    double prod[128];
+    for (i64 c = 0; c < ncomp; ++c) {
+        const double *f = field + c * nsrc;
+        for (i64 i = 0; i < npoints; ++i) {
+            for (i64 p = 0; p < P; ++p)
+                prod[p] = f[ids[i * P + p]] * w[i * P + p];
+            const double v = numpy_row_sum(prod, P);
+            if (out_point_major) out[i * ncomp + c] = v;
+            else out[c * npoints + i] = v;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* A2: exact k nearest neighbours by brute force (small cases only).   */
+/* The reference calls scipy.spatial.cKDTree(...).query(pts, k)        */
+/* (scripts/cli.py:66-73); scipy is a third-party dependency, so this  */
+/* restates its published contract: the k smallest Euclidean distances */
+/* in ascending order, squared distance accumulated axis by axis       */
+/* ((dx*dx + dy*dy) + dz*dz, no fused multiply-add).  Equal distances  */
+/* are ordered by index here (cKDTree's tie order is unspecified).     */
+/* Rows with fewer than k sources are padded with index nsrc and +inf  */
+/* like cKDTree.                                                       */
+/* ------------------------------------------------------------------ */
+void mmo_knn_brute(const double *src, i64 nsrc, const double *pts, i64 npts,
+                   i64 ndim, i64 k, i64 *idx, double *d2out)
+{
+    double *bd = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+    i64 *bi = (i64 *)malloc(sizeof(i64) * (size_t)(k > 0 ? k : 1));
+    for (i64 i = 0; i < npts; ++i) {
+        i64 have = 0;
+        for (i64 e = 0; e < nsrc; ++e) {
+            double d2 = 0.;
+            for (i64 a = 0; a < ndim; ++a) {
+                const double d = src[e * ndim + a] - pts[i * ndim + a];
+                d2 += d * d;
+            }
+            if (have == k && !(d2 < bd[k - 1])) continue; /* ties keep lower index */
+            i64 pos = have < k ? have : k - 1;
+            while (pos > 0 && d2 < bd[pos - 1]) {
+                bd[pos] = bd[pos - 1];
+                bi[pos] = bi[pos - 1];
+                --pos;
+            }
+            bd[pos] = d2;
+            bi[pos] = e;
+            if (have < k) ++have;
+        }
+        for (i64 j = 0; j < k; ++j) {
+            idx[i * k + j] = j < have ? bi[j] : nsrc;
+            if (d2out) d2out[i * k + j] = j < have ? bd[j] : INFINITY;
+        }
+    }
+    free(bd);
+    free(bi);
+}
