@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the mesh-to-mesh interpolation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the whole hot path (reference scripts/cli.py:62-100) over one batch of
+synthetic targets with every input already resident in HBM: element centroids -> search-grid
+build -> k nearest centroids -> hex8 Newton location -> weighted gather (-> one RCCL all-gather of
+the interpolated field when N > 1).  Workload = BASELINE.json's metric configuration: 10M -> 10M
+nodes (216^3 jittered hex meshes), 1 scalar field, k = 20.  Weak scaling: every rank interpolates
+its own 10M-node target mesh (different jitter seed) from the replicated source mesh.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     HBM roofline of the dominant kernel (algorithmic bytes / measured duration),
+  "stages":       the same accounting for every stage,
+  "cpu_baseline": the reference's CPU path timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from multimesh_amd import synth  # noqa: E402
+from multimesh_amd.helpers import STAGES  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+
+
+def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
+    """algorithmic bytes per launch of each stage (reference dtypes)."""
+    return {
+        "centroid": n_elem * (8 * 8 + 8 * 24 + 24),
+        "knn_build": n_elem * 24 * 2,                       # read centroids, write them cell-sorted
+        "knn_query": n_targets * (24 + 8 * k) + n_elem * 24,
+        "locate": n_targets * (24 + 8 * k + 64 + 192 + 128),
+        "gather": n_targets * (128 + 72 * ncomp),
+    }
+
+
+def cpu_baseline(pa, ca, pb, fields, k, sample_stride):
+    """The reference CPU path (cKDTree + compiled reference C + NumPy) on a bounded sample."""
+    from oracle import oracle as O
+    from scipy.spatial import cKDTree
+
+    use_ref = O.have_reference()
+    t0 = time.perf_counter()
+    cen = O.ref_centroid(ca, pa) if use_ref else O.centroid(ca, pa)
+    t_cen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tree = cKDTree(cen, balanced_tree=False)                 # reference scripts/cli.py:66
+    t_build = time.perf_counter() - t0
+    sample = np.ascontiguousarray(pb[::sample_stride])
+    t0 = time.perf_counter()
+    _, nn = tree.query(sample, k=k)                          # no workers= -> 1 core, as the reference
+    t_query = time.perf_counter() - t0
+    conn = synth.reorder_hex8(ca)
+    t0 = time.perf_counter()
+    if use_ref:
+        enc, w, nf = O.ref_locate_hex8(nn, conn, pa, sample)
+    else:
+        enc, w, nf = O.locate_hex8(nn, conn, pa, sample)
+    t_locate = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vals = O.gather_numpy(fields, enc, w)
+    t_gather = time.perf_counter() - t0
+    per_point = (t_query + t_locate + t_gather) / len(sample)
+    t_full = t_cen + t_build + per_point * len(pb)
+    return {
+        "value": len(pb) / t_full,
+        "unit": "points/s",
+        "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "sample": (f"full {len(cen)}-element source (centroid {t_cen:.2f}s + cKDTree build {t_build:.2f}s) + every "
+                   f"{sample_stride}th target ({len(sample)} points: query {t_query:.2f}s, locate {t_locate:.2f}s, "
+                   f"gather {t_gather:.3f}s), per-point cost extrapolated to {len(pb)} targets; "
+                   f"host has {os.cpu_count()} cores, path is single-threaded like the reference"),
+        "nfailed": int(nf),
+    }, (sample_stride, enc, w, vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="metric", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--n-src", type=int, default=0, help="override nodes per side of the source mesh")
+    ap.add_argument("--n-tgt", type=int, default=0, help="override nodes per side of the target mesh")
+    ap.add_argument("--ncomp", type=int, default=0)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-stride", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    n_src = args.n_src or cfg["n_src"]
+    n_tgt = args.n_tgt or cfg["n_tgt"]
+    ncomp = args.ncomp or cfg["ncomp"]
+    if args.workload == "cfg4" and not args.n_tgt:
+        # 100M targets sharded over 8 GPUs = 12.5M per GPU -> 233^3 nodes per rank
+        n_tgt = 233
+    k = args.k
+
+    # ---- synthetic inputs (host), then resident in HBM before any timing ----
+    pa, ca = synth.hex_mesh(n_src, seed=1)
+    pb, _ = synth.hex_mesh(n_tgt, seed=7 + rank)
+    fields = synth.vector_field(pa)[:ncomp]
+    t_nodes = torch.from_numpy(pa).to(dev)
+    t_conn = torch.from_numpy(ca).to(dev)
+    t_pts = torch.from_numpy(pb).to(dev)
+    t_fields = torch.from_numpy(fields).to(dev)
+    n_local = pb.shape[0]
+    t_out = torch.empty((n_local, ncomp), dtype=torch.float64, device=dev)
+    t_all = torch.empty((world * n_local, ncomp), dtype=torch.float64, device=dev) if world > 1 else None
+
+    from multimesh_amd.device import Context
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = Context(local_rank, stream=stream)
+    ctx.set_profiling(True)
+
+    stage_ms = {s: 0.0 for s in STAGES}
+    nfailed_total = 0
+
+    def step(record):
+        nonlocal nfailed_total
+        _, nf = ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, out=t_out)
+        if world > 1:
+            dist.all_gather_into_tensor(t_all, t_out)
+        if record:
+            nfailed_total += nf
+            for s, v in ctx.last_timings().items():
+                stage_ms[s] += v
+
+    for _ in range(args.warmup):
+        step(False)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nf_t = torch.tensor([nfailed_total], dtype=torch.int64, device=dev)
+        dist.all_reduce(nf_t)
+        nfailed_total = int(nf_t.item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed / steps * 1e3
+        total_targets = n_local * world
+        value = total_targets * steps / elapsed
+        n_elem, n_nodes = ca.shape[0], pa.shape[0]
+        abytes = algorithmic_bytes(n_local, n_elem, n_nodes, k, ncomp)
+        stages = {}
+        for s in STAGES:
+            ms = stage_ms[s] / steps
+            gbps = abytes[s] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            stages[s] = {"ms": round(ms, 4), "algorithmic_bytes": abytes[s], "achieved_GBps": round(gbps, 1),
+                         "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        dominant = max(STAGES, key=lambda s: stage_ms[s])
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": stages[dominant]["achieved_GBps"],
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": stages[dominant]["frac"], "traffic": None}
+        line = {
+            "metric": "interpolated points/sec, 10M->10M 3D mesh, 1 scalar field",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"hex8 3D {n_nodes}->{n_local} nodes per GPU (n_src={n_src}, n_tgt={n_tgt} per side, "
+                                   f"jittered unit cube), {ncomp} field component(s), k={k}",
+                       "source_nodes": n_nodes, "source_elements": n_elem, "targets_per_gpu": n_local,
+                       "parallelism": f"targets sharded x{world}, source replicated, 1 all-gather" if world > 1
+                       else "single GPU"},
+            "nfailed": nfailed_total,
+            "roofline": roofline,
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            stride = args.cpu_sample_stride or max(1, n_local // 1_000_000)
+            base, (stride, enc_c, w_c, vals_c) = cpu_baseline(pa, ca, pb, fields, k, stride)
+            line["cpu_baseline"] = base
+            line["speedup_vs_cpu_baseline"] = value / base["value"]
+            # parity gate on the sample the CPU just computed
+            got = t_out.cpu().numpy()[::stride]
+            line["parity_vs_cpu_sample"] = bool(np.array_equal(got, vals_c))
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

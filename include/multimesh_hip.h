@@ -1,0 +1,155 @@
+/*
+ * multimesh_hip.h -- C ABI of multi_mesh_hip.so, the MI355X (gfx950) drop-in for the
+ * MultiMesh interpolation hot path: element centroids -> k nearest centroids ->
+ * point-in-hex8 location by Newton inversion -> shape-function weighted gather.
+ *
+ * Plain pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) LEGACY symbols with the exact signature and semantics of the reference's own C
+ *      library (what reference multi_mesh/helpers.py:43-81 binds).  Host pointers in,
+ *      host pointers out; the work runs on the GPU.
+ *  (2) mm_* symbols taking DEVICE pointers, for callers that keep meshes resident in HBM
+ *      (the benchmark, the multi-GPU driver, repeated queries against one source mesh).
+ *
+ * Error convention: the reference has no error channel (per-point failures are a count,
+ * reference src/trilinearinterpolator.c:133-147).  Here: int / int64 returns are >= 0 on
+ * success (a failed-point count where the reference returns one) and NEGATIVE MM_ERR_* on a
+ * runtime error; mm_last_error() returns a message.  There is no CPU fallback: without a
+ * usable GPU every compute entry point fails with MM_ERR_NODEVICE / MM_ERR_HIP.
+ * Nothing is ever printed from device code (the reference's "not any" printf is dropped).
+ */
+#ifndef MULTIMESH_HIP_H
+#define MULTIMESH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_OK 0
+#define MM_ERR_ARG (-1)         /* bad argument (null pointer, negative size, k too large ...) */
+#define MM_ERR_HIP (-2)         /* a HIP runtime call failed; see mm_last_error() */
+#define MM_ERR_NODEVICE (-3)    /* no usable GPU */
+#define MM_ERR_ALLOC (-4)       /* device or host allocation failed */
+#define MM_ERR_UNSUPPORTED (-5) /* valid request this build does not implement */
+
+#define MM_KNN_MAX_K 64 /* largest nelem_to_search served (reference uses 20, 25, 30) */
+
+/* ------------------------------------------------------------------------------------
+ * (1) Legacy symbols -- replace the reference library one for one.
+ * ---------------------------------------------------------------------------------- */
+
+/* Replaces reference src/centroid.c:3-9 (bound at helpers.py:43-57).
+ * centroid[e][a] = (sum over the element's nodes, in connectivity order) / npointsperelem.
+ * connectivity int64[nelem][npointsperelem], points f64[npoints][ndim], centroid
+ * f64[nelem][ndim], all C-contiguous host arrays.  ndim in {1,2,3}.  The signature has no
+ * error channel: on failure the output is left untouched, a message goes to stderr and
+ * mm_last_error()/mm_last_status() report it. */
+void centroid(long long ndim, long long nelem, long long npointsperelem,
+              long long *connectivity, double *points, double *centroid);
+
+/* Replaces reference src/trilinearinterpolator.c:40-48 (bound at helpers.py:59-81).
+ * For each of npoints targets walk its nelem_to_search candidate elements in the given
+ * order, Newton-invert the trilinear map, accept the first with max|xi| < 1.025, else after
+ * the last candidate fall back to the least-outside one if < 1.5; write the element's 8
+ * node ids and 8 weights in place; rows of failed points are left untouched.  Returns the
+ * number of failed points (>= 0) or a negative MM_ERR_*.  Host arrays:
+ * nearest_element_indices int64[npoints][k], connectivity int64[nelem][8] (locator corner
+ * order), enclosing_elem_indices int64[npoints][8] out, nodes f64[nnodes][3], weights
+ * f64[npoints][8] out, points f64[npoints][3].  nelem / nnodes are not in the reference
+ * signature; they are recovered as max index + 1. */
+long long triLinearInterpolator(long long nelem_to_search, long long npoints,
+                                long long *nearest_element_indices, long long *connectivity,
+                                long long *enclosing_elem_indices, double *nodes,
+                                double *weights, double *points);
+
+/* ------------------------------------------------------------------------------------
+ * (2) Device-pointer API.
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct mm_context mm_context;     /* device, stream, scratch pool, stage timers */
+typedef struct mm_knn_index mm_knn_index; /* device-resident search grid over source points */
+
+int mm_device_count(void);
+const char *mm_last_error(void); /* thread-local message of the last failure */
+int mm_last_status(void);        /* thread-local MM_* code of the last legacy call */
+
+/* hip_stream: a hipStream_t (NULL = the device's default stream).  All work of a context is
+ * issued on that stream; entry points that return a count synchronise it. */
+int mm_context_create(int device, void *hip_stream, mm_context **out);
+void mm_context_destroy(mm_context *ctx);
+int mm_synchronize(mm_context *ctx);
+
+/* Resident-array helpers for hosts that have no other device allocator. */
+int mm_device_alloc(mm_context *ctx, size_t bytes, void **dptr);
+int mm_device_free(mm_context *ctx, void *dptr);
+int mm_copy_h2d(mm_context *ctx, void *dst_d, const void *src_h, size_t bytes);
+int mm_copy_d2h(mm_context *ctx, void *dst_h, const void *src_d, size_t bytes);
+int mm_memset(mm_context *ctx, void *dst_d, int value, size_t bytes);
+
+/* A1 -- element centroids (reference src/centroid.c:3-25), device arrays. */
+int mm_centroid(mm_context *ctx, int64_t ndim, int64_t nelem, int64_t npointsperelem,
+                const int64_t *connectivity_d, const double *points_d, double *centroid_d);
+
+/* A2 -- exact k nearest neighbours; replaces scipy.spatial.cKDTree(src, balanced_tree=False)
+ * + .query(pts, k) at reference scripts/cli.py:66-73.  build = the tree construction,
+ * query = .query: idx_d int64[npts][k] ascending by Euclidean distance (squared distance
+ * summed axis by axis in fp64, no fused multiply-add; equal distances ordered by index);
+ * rows with fewer than k sources are padded with index nsrc (distance inf) like cKDTree.
+ * dist_d (nullable) f64[npts][k] receives the distances.  ndim in {1,2,3}; k <= MM_KNN_MAX_K. */
+int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, int64_t ndim,
+                 mm_knn_index **out);
+int mm_knn_query(mm_context *ctx, const mm_knn_index *index, const double *pts_d, int64_t npts,
+                 int64_t k, int64_t *idx_d, double *dist_d);
+void mm_knn_destroy(mm_context *ctx, mm_knn_index *index);
+
+/* A4..A8 -- hex8 point location + weights (reference src/trilinearinterpolator.c:40-148),
+ * device arrays, same in-place contract as the legacy symbol.  nelem > 0 enables a bounds
+ * guard: candidates outside [0, nelem) (cKDTree's padding) count as "not in hull".
+ * conn_is_exodus != 0 applies the reference's host-side column reorder
+ * (scripts/cli.py:79-81) on the fly, so the caller can pass the mesh's own connectivity. */
+int64_t mm_locate_hex8(mm_context *ctx, int64_t nelem_to_search, int64_t npoints,
+                       const int64_t *nearest_element_indices_d, const int64_t *connectivity_d,
+                       int64_t nelem, int conn_is_exodus, int64_t *enclosing_elem_indices_d,
+                       const double *nodes_d, double *weights_d, const double *points_d);
+
+/* A9 -- weighted gather; replaces np.sum(field[enc] * w, axis=1) at reference
+ * scripts/cli.py:98-100 (P = 8) and interpolator.py:976 (P = 27, 125), NumPy's summation
+ * order.  fields_d f64[ncomp][nsrc] (one contiguous array per parameter, as the reference
+ * keeps them); ids_d int64[npoints][P]; w_d f64[npoints][P]; out_d f64[npoints][ncomp] when
+ * out_point_major (the layout reference interpolator.py:973-977 returns) else
+ * f64[ncomp][npoints].  P <= 128. */
+int mm_gather(mm_context *ctx, const double *fields_d, int64_t nsrc, int64_t ncomp,
+              const int64_t *ids_d, const double *w_d, int64_t npoints, int64_t P, double *out_d,
+              int out_point_major);
+
+/* The whole hot path of reference scripts/cli.py:62-100 on resident arrays:
+ * centroid -> search grid -> kNN -> locate -> gather.  connectivity_d is the mesh's own
+ * (exodus-order) hex8 connectivity.  enc_d / w_d (nullable) receive the interpolation
+ * operator (int64[N][8], f64[N][8]); out_d f64[N][ncomp] (nullable when only the operator is
+ * wanted).  Returns the number of failed points or a negative MM_ERR_*. */
+int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnodes,
+                            const int64_t *connectivity_d, int64_t nelem, const double *points_d,
+                            int64_t npoints, const double *fields_d, int64_t ncomp,
+                            int64_t nelem_to_search, double *out_d, int64_t *enc_d, double *w_d);
+
+/* Stage timers (hipEvents on the context's stream).  With profiling on, every kernel
+ * launched by the calls above is bracketed by events; mm_last_timings fills ms[stage] for
+ * the stages of the LAST call (0 for stages that did not run) and returns the stage count. */
+enum mm_stage {
+    MM_STAGE_CENTROID = 0,
+    MM_STAGE_KNN_BUILD = 1,
+    MM_STAGE_KNN_QUERY = 2,
+    MM_STAGE_LOCATE = 3,
+    MM_STAGE_GATHER = 4,
+    MM_STAGE_COUNT = 5
+};
+int mm_set_profiling(mm_context *ctx, int on);
+int mm_last_timings(mm_context *ctx, double *ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTIMESH_HIP_H */

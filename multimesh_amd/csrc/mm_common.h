@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of multi_mesh_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "multimesh_hip.h"
+
+typedef long long i64;
+
+void mm_set_error(int code, const char *fmt, ...);
+
+#define MM_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            mm_set_error(MM_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,      \
+                         hipGetErrorString(_e));                                        \
+            return MM_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define MM_REQUIRE(cond, msg)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            mm_set_error(MM_ERR_ARG, "%s: %s", __func__, msg);                          \
+            return MM_ERR_ARG;                                                          \
+        }                                                                               \
+    } while (0)
+
+// Grow-only device scratch: bump-allocated within one API call, reset at the start of the
+// next.  Growing frees the old block after synchronising the stream (only while warming up).
+struct mm_scratch {
+    char *base = nullptr;
+    size_t capacity = 0;
+    size_t used = 0;
+};
+
+struct mm_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mm_scratch scratch;
+    // failed-point counter + small readback area (device) and its pinned host mirror
+    i64 *d_counters = nullptr;
+    i64 *h_counters = nullptr;
+    // stage timers
+    int profiling = 0;
+    hipEvent_t ev_begin[MM_STAGE_COUNT];
+    hipEvent_t ev_end[MM_STAGE_COUNT];
+    bool ev_used[MM_STAGE_COUNT];
+    bool ev_created = false;
+};
+
+// Reserve `total` bytes of scratch for the current call (may reallocate), then carve with
+// mm_scratch_take.  All carve sizes are rounded up to 256 B.
+int mm_scratch_begin(mm_context *ctx, size_t total);
+void *mm_scratch_take(mm_context *ctx, size_t bytes);
+static inline size_t mm_round256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Stage timing helpers: no-ops unless profiling is on.
+void mm_stage_reset(mm_context *ctx);
+void mm_stage_begin(mm_context *ctx, int stage);
+void mm_stage_end(mm_context *ctx, int stage);
+
+// ---- internal launchers (device pointers, no synchronisation) -------------------------
+int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,
+                       const double *points, double *out);
+int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const i64 *conn,
+                          i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes,
+                          double *w, const double *pts, i64 *d_nfailed);
+int mm_launch_gather(mm_context *ctx, const double *fields, i64 nsrc, i64 ncomp, const i64 *ids,
+                     const double *w, i64 npoints, i64 P, double *out, int out_point_major);
+
+// kNN search grid over source points (device resident).
+struct mm_knn_index {
+    i64 nsrc = 0;
+    int ndim = 3;
+    int dims[3] = {1, 1, 1};       // cells per axis
+    double lo[3] = {0, 0, 0};      // bounding-box minimum
+    double h[3] = {1, 1, 1};       // cell edge per axis
+    double inv_h[3] = {1, 1, 1};
+    i64 ncells = 1;
+    int *cell_start = nullptr;     // [ncells + 1] exclusive prefix of per-cell counts
+    double *sorted_xyz = nullptr;  // [nsrc][3] source coordinates in cell order (z padded 0)
+    int *sorted_id = nullptr;      // [nsrc] original index of each sorted source
+};

@@ -1,0 +1,223 @@
+// Context, error reporting, scratch pool, stage timers and resident-array helpers.
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+
+#include "mm_common.h"
+
+static thread_local char g_err[512] = "";
+static thread_local int g_status = MM_OK;
+
+void mm_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    g_status = code;
+}
+
+extern "C" const char *mm_last_error(void) { return g_err; }
+extern "C" int mm_last_status(void) { return g_status; }
+void mm_clear_status(void) { g_status = MM_OK; }
+
+extern "C" int mm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mm_context_create(int device, void *hip_stream, mm_context **out)
+{
+    MM_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        mm_set_error(MM_ERR_NODEVICE, "no usable GPU (hipGetDeviceCount found none); "
+                                      "multi_mesh_hip has no CPU fallback");
+        return MM_ERR_NODEVICE;
+    }
+    MM_REQUIRE(device >= 0 && device < n, "device index out of range");
+    MM_HIP_CHECK(hipSetDevice(device));
+    mm_context *ctx = new (std::nothrow) mm_context();
+    if (!ctx) {
+        mm_set_error(MM_ERR_ALLOC, "out of host memory");
+        return MM_ERR_ALLOC;
+    }
+    ctx->device = device;
+    ctx->stream = (hipStream_t)hip_stream;
+    hipError_t e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(i64));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(i64), 0);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        delete ctx;
+        return MM_ERR_HIP;
+    }
+    for (int s = 0; s < MM_STAGE_COUNT; ++s) ctx->ev_used[s] = false;
+    *out = ctx;
+    return MM_OK;
+}
+
+extern "C" void mm_context_destroy(mm_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev_created)
+        for (int s = 0; s < MM_STAGE_COUNT; ++s) {
+            (void)hipEventDestroy(ctx->ev_begin[s]);
+            (void)hipEventDestroy(ctx->ev_end[s]);
+        }
+    delete ctx;
+}
+
+extern "C" int mm_synchronize(mm_context *ctx)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MM_OK;
+}
+
+extern "C" int mm_device_alloc(mm_context *ctx, size_t bytes, void **dptr)
+{
+    MM_REQUIRE(ctx != nullptr && dptr != nullptr, "null argument");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return MM_ERR_ALLOC;
+    }
+    return MM_OK;
+}
+
+extern "C" int mm_device_free(mm_context *ctx, void *dptr)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    if (!dptr) return MM_OK;
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MM_HIP_CHECK(hipFree(dptr));
+    return MM_OK;
+}
+
+extern "C" int mm_copy_h2d(mm_context *ctx, void *dst_d, const void *src_h, size_t bytes)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    if (bytes == 0) return MM_OK;
+    MM_REQUIRE(dst_d != nullptr && src_h != nullptr, "null pointer");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    MM_HIP_CHECK(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MM_OK;
+}
+
+extern "C" int mm_copy_d2h(mm_context *ctx, void *dst_h, const void *src_d, size_t bytes)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    if (bytes == 0) return MM_OK;
+    MM_REQUIRE(dst_h != nullptr && src_d != nullptr, "null pointer");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    MM_HIP_CHECK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MM_OK;
+}
+
+extern "C" int mm_memset(mm_context *ctx, void *dst_d, int value, size_t bytes)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    if (bytes == 0) return MM_OK;
+    MM_REQUIRE(dst_d != nullptr, "null pointer");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    MM_HIP_CHECK(hipMemsetAsync(dst_d, value, bytes, ctx->stream));
+    return MM_OK;
+}
+
+// ---- scratch -----------------------------------------------------------------------
+int mm_scratch_begin(mm_context *ctx, size_t total)
+{
+    total = mm_round256(total) + 4096;
+    if (total > ctx->scratch.capacity) {
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch.base) MM_HIP_CHECK(hipFree(ctx->scratch.base));
+        ctx->scratch.base = nullptr;
+        ctx->scratch.capacity = 0;
+        size_t want = total + total / 8;
+        hipError_t e = hipMalloc((void **)&ctx->scratch.base, want);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_ALLOC, "scratch hipMalloc(%zu) failed: %s", want,
+                         hipGetErrorString(e));
+            return MM_ERR_ALLOC;
+        }
+        ctx->scratch.capacity = want;
+    }
+    ctx->scratch.used = 0;
+    return MM_OK;
+}
+
+void *mm_scratch_take(mm_context *ctx, size_t bytes)
+{
+    bytes = mm_round256(bytes);
+    if (ctx->scratch.used + bytes > ctx->scratch.capacity) return nullptr;
+    void *p = ctx->scratch.base + ctx->scratch.used;
+    ctx->scratch.used += bytes;
+    return p;
+}
+
+// ---- stage timers ------------------------------------------------------------------
+extern "C" int mm_set_profiling(mm_context *ctx, int on)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (on && !ctx->ev_created) {
+        for (int s = 0; s < MM_STAGE_COUNT; ++s) {
+            MM_HIP_CHECK(hipEventCreate(&ctx->ev_begin[s]));
+            MM_HIP_CHECK(hipEventCreate(&ctx->ev_end[s]));
+        }
+        ctx->ev_created = true;
+    }
+    ctx->profiling = on ? 1 : 0;
+    return MM_OK;
+}
+
+void mm_stage_reset(mm_context *ctx)
+{
+    for (int s = 0; s < MM_STAGE_COUNT; ++s) ctx->ev_used[s] = false;
+}
+
+void mm_stage_begin(mm_context *ctx, int stage)
+{
+    if (!ctx->profiling) return;
+    (void)hipEventRecord(ctx->ev_begin[stage], ctx->stream);
+}
+
+void mm_stage_end(mm_context *ctx, int stage)
+{
+    if (!ctx->profiling) return;
+    (void)hipEventRecord(ctx->ev_end[stage], ctx->stream);
+    ctx->ev_used[stage] = true;
+}
+
+extern "C" int mm_last_timings(mm_context *ctx, double *ms, int n)
+{
+    MM_REQUIRE(ctx != nullptr && ms != nullptr, "null argument");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int s = 0; s < n; ++s) ms[s] = 0.0;
+    if (!ctx->profiling) return MM_STAGE_COUNT;
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < MM_STAGE_COUNT && s < n; ++s) {
+        if (!ctx->ev_used[s]) continue;
+        float t = 0.f;
+        MM_HIP_CHECK(hipEventElapsedTime(&t, ctx->ev_begin[s], ctx->ev_end[s]));
+        ms[s] = (double)t;
+    }
+    return MM_STAGE_COUNT;
+}

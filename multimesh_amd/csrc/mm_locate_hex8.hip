@@ -1,0 +1,293 @@
+// A4..A8 -- hex8 point location by Newton inversion + trilinear weights.
+// Replaces reference multi_mesh/src/trilinearinterpolator.c:40-148 (triLinearInterpolator) and
+// its helpers :150-375.
+//
+// One lane per target point.  The lane walks its candidate elements in the given (kNN) order;
+// for each it gathers the 8 corner ids and coordinates, runs the fp64 Newton iteration entirely
+// in registers and applies the reference's acceptance rules:
+//   * hull check: converged (<= 50 iterations, tolerance 1e-8 * max|v1-v0|, residual test on
+//     x, y and x again -- z is never tested, trilinearinterpolator.c:290-291) and all |xi| <= 2;
+//   * accept the first candidate with max|xi| < 1.025 (:93);
+//   * otherwise remember the candidate with the smallest max|xi| (:105-110) and, after the last
+//     candidate, re-run it and use it if that value is < 1.5 (:113-132); else the point fails
+//     (:133-143) and its output rows are left untouched.
+// Every floating-point expression keeps the reference's association order and the file is built
+// with -ffp-contract=off, so node ids AND weights are bit-identical to the reference.
+//
+// HBM-bound by the roofline accounting (568 B/target when the first candidate is accepted:
+// 24 point + 8k candidates + 64 connectivity row + 192 corner coordinates + 128 out), though
+// the lane spends most of its time in the dependent Newton chain; corner gathers hit L2.
+#include "mm_common.h"
+
+namespace {
+
+// Forward map of one axis (trilinearinterpolator.c:199-212) with named partials; each partial is
+// the same rounded quantity the reference's single expression produces.
+__device__ __forceinline__ double map_axis(const double (&v)[8], double hr, double hs, double ht)
+{
+    const double e03 = hr * (-v[0] + v[3]);
+    const double e12 = hr * (-v[1] + v[2]);
+    const double e45 = hr * (-v[4] + v[5]);
+    const double e76 = hr * (v[6] - v[7]);
+    const double bottom_s = hs * (((-v[0] + v[1]) - e03) + e12);
+    const double top_s = hs * (((-v[4] + v[7]) - e45) + e76);
+    const double along_t = ht * (((((-v[0] + v[4]) - e03) + e45) - bottom_s) + top_s);
+    return ((v[0] + e03) + bottom_s) + along_t;
+}
+
+// corner signs of trilinearinterpolator.c:8-10
+#define MM_R(n) ((n) == 2 || (n) == 3 || (n) == 5 || (n) == 6 ? 1.0 : -1.0)
+#define MM_S(n) ((n) == 1 || (n) == 2 || (n) == 6 || (n) == 7 ? 1.0 : -1.0)
+#define MM_T(n) ((n) >= 4 ? 1.0 : -1.0)
+
+// Newton inversion (trilinearinterpolator.c:260-305).  x/y/z hold the corner coordinates per
+// axis.  Returns true when converged; xi receives the last iterate either way.
+__device__ __forceinline__ bool newton_hex8(const double px, const double py, const double pz,
+                                            const double (&x)[8], const double (&y)[8],
+                                            const double (&z)[8], double (&xi)[3])
+{
+    xi[0] = 0.;
+    xi[1] = 0.;
+    xi[2] = 0.;
+    const double sx = fabs(x[1] - x[0]);
+    const double sy = fabs(y[1] - y[0]);
+    const double sz = fabs(z[1] - z[0]);
+    const double sxy = sx > sy ? sx : sy;
+    const double scale = sz > sxy ? sz : sxy;
+    const double tol = 1e-8 * scale;
+    for (int it = 0; it < 50; ++it) {
+        const double hr = 0.5 * (xi[0] + 1.0);
+        const double hs = 0.5 * (xi[1] + 1.0);
+        const double ht = 0.5 * (xi[2] + 1.0);
+        const double r0 = px - map_axis(x, hr, hs, ht);
+        const double r1 = py - map_axis(y, hr, hs, ht);
+        const double r2 = pz - map_axis(z, hr, hs, ht);
+        if (fabs(r0) < tol && fabs(r1) < tol) return true;  // z is never tested (reference quirk)
+        // Jacobian m[q][j] = sum_n dN_n/dxi_q * corner_n[j], accumulated from 0 in node order
+        double m[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            m[q][0] = 0.;
+            m[q][1] = 0.;
+            m[q][2] = 0.;
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const double fs = xi[1] * MM_S(n) + 1;
+            const double ft = xi[2] * MM_T(n) + 1;
+            const double fr = xi[0] * MM_R(n) + 1;
+            const double d0 = 0.125 * MM_R(n) * fs * ft;
+            const double d1 = 0.125 * MM_S(n) * fr * ft;
+            const double d2 = 0.125 * MM_T(n) * fr * fs;
+            m[0][0] = m[0][0] + d0 * x[n];
+            m[0][1] = m[0][1] + d0 * y[n];
+            m[0][2] = m[0][2] + d0 * z[n];
+            m[1][0] = m[1][0] + d1 * x[n];
+            m[1][1] = m[1][1] + d1 * y[n];
+            m[1][2] = m[1][2] + d1 * z[n];
+            m[2][0] = m[2][0] + d2 * x[n];
+            m[2][1] = m[2][1] + d2 * y[n];
+            m[2][2] = m[2][2] + d2 * z[n];
+        }
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) -
+                           m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        const double rdet = 1 / det;
+        const double i00 = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * rdet;
+        const double i01 = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * rdet;
+        const double i02 = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * rdet;
+        const double i10 = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * rdet;
+        const double i11 = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * rdet;
+        const double i12 = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * rdet;
+        const double i20 = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * rdet;
+        const double i21 = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * rdet;
+        const double i22 = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * rdet;
+        // update = (J^-1)^T * residual, each row summed from 0 (trilinearinterpolator.c:362-375)
+        const double u0 = ((0. + i00 * r0) + i10 * r1) + i20 * r2;
+        const double u1 = ((0. + i01 * r0) + i11 * r1) + i21 * r2;
+        const double u2 = ((0. + i02 * r0) + i12 * r1) + i22 * r2;
+        xi[0] = xi[0] + u0;
+        xi[1] = xi[1] + u1;
+        xi[2] = xi[2] + u2;
+    }
+    return false;
+}
+
+// Eight weights as expanded polynomials (trilinearinterpolator.c:174-197); the sign rides on
+// the exact constant 0.125 and the terms are added strictly left to right.
+__device__ __forceinline__ void weights_hex8(const double (&xi)[3], double (&w)[8])
+{
+    const double r = xi[0], s = xi[1], t = xi[2];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        // signs: rst = R*S*T, rs = -(R*S*T)*T ... derived from the node's corner signs
+        const double R = MM_R(n), S = MM_S(n), T = MM_T(n);
+        const double c_rst = 0.125 * (R * S * T);
+        const double c_rs = 0.125 * (R * S);
+        const double c_rt = 0.125 * (R * T);
+        const double c_r = 0.125 * R;
+        const double c_st = 0.125 * (S * T);
+        const double c_s = 0.125 * S;
+        const double c_t = 0.125 * T;
+        double acc = c_rst * r * s * t;
+        acc = acc + c_rs * r * s;
+        acc = acc + c_rt * r * t;
+        acc = acc + c_r * r;
+        acc = acc + c_st * s * t;
+        acc = acc + c_s * s;
+        acc = acc + c_t * t;
+        acc = acc + 0.125;
+        w[n] = acc;
+    }
+}
+
+struct Corners {
+    i64 id[8];
+    double x[8], y[8], z[8];
+};
+
+template <bool EXODUS>
+__device__ __forceinline__ void load_corners(const i64 *__restrict__ conn,
+                                             const double *__restrict__ nodes, i64 elem, Corners &c)
+{
+    const longlong2 *row = reinterpret_cast<const longlong2 *>(conn + elem * 8);
+    const longlong2 a = row[0], b = row[1], cc = row[2], d = row[3];
+    c.id[0] = a.x;
+    c.id[1] = EXODUS ? b.y : a.y;  // reference scripts/cli.py:79-81: columns 1 and 3 swap
+    c.id[2] = b.x;
+    c.id[3] = EXODUS ? a.y : b.y;
+    c.id[4] = cc.x;
+    c.id[5] = cc.y;
+    c.id[6] = d.x;
+    c.id[7] = d.y;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const double *p = nodes + c.id[n] * 3;
+        c.x[n] = p[0];
+        c.y[n] = p[1];
+        c.z[n] = p[2];
+    }
+}
+
+__device__ __forceinline__ double max_abs3(const double (&xi)[3])
+{
+    double worst = 0.0;
+    if (fabs(xi[0]) > worst) worst = fabs(xi[0]);
+    if (fabs(xi[1]) > worst) worst = fabs(xi[1]);
+    if (fabs(xi[2]) > worst) worst = fabs(xi[2]);
+    return worst;
+}
+
+__device__ __forceinline__ bool in_hull(const double (&xi)[3])
+{
+    return !(fabs(xi[0]) > (1 + 1.0)) && !(fabs(xi[1]) > (1 + 1.0)) && !(fabs(xi[2]) > (1 + 1.0));
+}
+
+__device__ __forceinline__ void store_row(i64 *__restrict__ enc, double *__restrict__ w, i64 i,
+                                          const Corners &c, const double (&wt)[8])
+{
+    longlong2 *e2 = reinterpret_cast<longlong2 *>(enc + i * 8);
+    double2 *w2 = reinterpret_cast<double2 *>(w + i * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        e2[q] = make_longlong2(c.id[2 * q], c.id[2 * q + 1]);
+        w2[q] = make_double2(wt[2 * q], wt[2 * q + 1]);
+    }
+}
+
+template <bool EXODUS>
+__global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
+                                                          const i64 *__restrict__ nn,
+                                                          const i64 *__restrict__ conn, i64 nelem,
+                                                          i64 *__restrict__ enc,
+                                                          const double *__restrict__ nodes,
+                                                          double *__restrict__ w,
+                                                          const double *__restrict__ pts,
+                                                          unsigned long long *__restrict__ nfailed)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool failed = false;
+    if (i < npoints && k > 0) {
+        const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+        double smallest = 99999999.9;
+        i64 best = -1;
+        bool found = false;
+        Corners c;
+        double xi[3], wt[8];
+        for (i64 j = 0; j < k; ++j) {
+            const i64 elem = nn[i * k + j];
+            if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
+            load_corners<EXODUS>(conn, nodes, elem, c);
+            if (newton_hex8(px, py, pz, c.x, c.y, c.z, xi) && in_hull(xi)) {
+                const double worst = max_abs3(xi);
+                if (worst < (1 + 0.025)) {
+                    weights_hex8(xi, wt);
+                    store_row(enc, w, i, c, wt);
+                    found = true;
+                    break;
+                } else if (worst < smallest) {
+                    smallest = worst;
+                    best = elem;
+                }
+            }
+        }
+        if (!found) {
+            bool ok = false;
+            if (smallest < 1.5 && best >= 0) {
+                load_corners<EXODUS>(conn, nodes, best, c);
+                if (newton_hex8(px, py, pz, c.x, c.y, c.z, xi) && in_hull(xi)) {
+                    weights_hex8(xi, wt);
+                    store_row(enc, w, i, c, wt);
+                    ok = true;
+                }
+            }
+            failed = !ok;
+        }
+    }
+    const unsigned long long mask = __ballot(failed);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nfailed, (unsigned long long)__popcll(mask));
+}
+
+}  // namespace
+
+int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const i64 *conn,
+                          i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w,
+                          const double *pts, i64 *d_nfailed)
+{
+    MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
+    if (npoints == 0 || k == 0) return MM_OK;
+    const int block = 256;
+    const i64 grid = (npoints + block - 1) / block;
+    MM_REQUIRE(grid < (i64)0x7fffffff, "too many targets for one launch");
+    dim3 g((unsigned)grid), b(block);
+    if (conn_is_exodus)
+        hipLaunchKernelGGL((locate_hex8_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                           enc, nodes, w, pts, (unsigned long long *)d_nfailed);
+    else
+        hipLaunchKernelGGL((locate_hex8_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                           enc, nodes, w, pts, (unsigned long long *)d_nfailed);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
+extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, const int64_t *nn_d,
+                                  const int64_t *conn_d, int64_t nelem, int conn_is_exodus,
+                                  int64_t *enc_d, const double *nodes_d, double *w_d,
+                                  const double *pts_d)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(k >= 0 && npoints >= 0, "negative size");
+    MM_REQUIRE(npoints == 0 || k == 0 || (nn_d && conn_d && enc_d && nodes_d && w_d && pts_d),
+               "null array");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    mm_stage_begin(ctx, MM_STAGE_LOCATE);
+    int rc = mm_launch_locate_hex8(ctx, k, npoints, (const i64 *)nn_d, (const i64 *)conn_d, nelem,
+                                   conn_is_exodus, (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters);
+    mm_stage_end(ctx, MM_STAGE_LOCATE);
+    if (rc != MM_OK) return rc;
+    MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ctx->h_counters[0];
+}

@@ -1,0 +1,250 @@
+// The fused hot path on resident arrays (mm_interpolate_hex8) and the two LEGACY host-pointer
+// symbols that replace the reference's C library one for one (reference multi_mesh/helpers.py:43-81
+// binds them; reference scripts/cli.py:62-100 is the call sequence the fused entry reproduces).
+#include <mutex>
+
+#include "mm_common.h"
+
+int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out);
+int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, i64 *idx_d,
+                      double *dist_d);
+void mm_clear_status(void);
+
+// -----------------------------------------------------------------------------------------
+// Fused pipeline: centroid -> grid build -> kNN -> locate -> gather.
+// Intermediates (centroids, candidate lists, and the operator when the caller does not ask for
+// it) live in caller-invisible device memory owned by this call.
+// -----------------------------------------------------------------------------------------
+extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnodes,
+                                       const int64_t *conn_d, int64_t nelem, const double *points_d,
+                                       int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
+                                       double *out_d, int64_t *enc_d, double *w_d)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(nnodes >= 1 && nelem >= 1, "empty source mesh");
+    MM_REQUIRE(npoints >= 0 && ncomp >= 0, "negative size");
+    MM_REQUIRE(k >= 1 && k <= MM_KNN_MAX_K, "nelem_to_search must be in 1..MM_KNN_MAX_K");
+    MM_REQUIRE(nodes_d && conn_d, "null mesh array");
+    MM_REQUIRE(npoints == 0 || points_d, "null target array");
+    MM_REQUIRE(ncomp == 0 || out_d == nullptr || fields_d, "null field array");
+    MM_REQUIRE(nelem < (int64_t)0x7fffffff, "too many elements");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    if (npoints == 0) return 0;
+
+    // Device buffers for this call.  The kNN build uses the context scratch itself, so the
+    // pipeline's own intermediates are separate allocations (freed at the end; the benchmark
+    // and the drivers reuse a context, so a caching layer can replace this later).
+    double *cen = nullptr;
+    i64 *nn = nullptr;
+    i64 *enc = (i64 *)enc_d;
+    double *w = w_d;
+    bool own_enc = false, own_w = false;
+    mm_knn_index *index = nullptr;
+    int64_t result = MM_ERR_HIP;
+    hipError_t e = hipSuccess;
+    int rc = MM_OK;
+
+#define MM_PIPE_FAIL(code, msg)                                        \
+    do {                                                               \
+        mm_set_error(code, "mm_interpolate_hex8: %s", msg);            \
+        result = code;                                                 \
+        goto done;                                                     \
+    } while (0)
+
+    e = hipMalloc((void **)&cen, (size_t)nelem * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&nn, (size_t)npoints * (size_t)k * sizeof(i64));
+    if (e == hipSuccess && !enc) {
+        e = hipMalloc((void **)&enc, (size_t)npoints * 8 * sizeof(i64));
+        own_enc = true;
+    }
+    if (e == hipSuccess && !w) {
+        e = hipMalloc((void **)&w, (size_t)npoints * 8 * sizeof(double));
+        own_w = true;
+    }
+    if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_ALLOC, hipGetErrorString(e));
+
+    // rows of failed points must read as zero (the reference's callers zero-initialise,
+    // scripts/cli.py:77-78)
+    e = hipMemsetAsync(enc, 0, (size_t)npoints * 8 * sizeof(i64), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w, 0, (size_t)npoints * 8 * sizeof(double), ctx->stream);
+    if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_HIP, hipGetErrorString(e));
+
+    mm_stage_begin(ctx, MM_STAGE_CENTROID);
+    rc = mm_launch_centroid(ctx, 3, nelem, 8, (const i64 *)conn_d, nodes_d, cen);
+    mm_stage_end(ctx, MM_STAGE_CENTROID);
+    if (rc != MM_OK) { result = rc; goto done; }
+
+    mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
+    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index);
+    mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
+    if (rc != MM_OK) { result = rc; goto done; }
+
+    mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
+    rc = mm_knn_query_impl(ctx, index, points_d, npoints, k, nn, nullptr);
+    mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
+    if (rc != MM_OK) { result = rc; goto done; }
+
+    mm_stage_begin(ctx, MM_STAGE_LOCATE);
+    rc = mm_launch_locate_hex8(ctx, k, npoints, nn, (const i64 *)conn_d, nelem, /*exodus=*/1, enc, nodes_d, w,
+                               points_d, ctx->d_counters);
+    mm_stage_end(ctx, MM_STAGE_LOCATE);
+    if (rc != MM_OK) { result = rc; goto done; }
+
+    if (out_d && ncomp > 0) {
+        mm_stage_begin(ctx, MM_STAGE_GATHER);
+        rc = mm_launch_gather(ctx, fields_d, nnodes, ncomp, enc, w, npoints, 8, out_d, 1);
+        mm_stage_end(ctx, MM_STAGE_GATHER);
+        if (rc != MM_OK) { result = rc; goto done; }
+    }
+    e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_HIP, hipGetErrorString(e));
+    result = ctx->h_counters[0];
+
+done:
+    (void)hipStreamSynchronize(ctx->stream);
+    if (index) mm_knn_destroy(nullptr, index);
+    if (cen) (void)hipFree(cen);
+    if (nn) (void)hipFree(nn);
+    if (own_enc && enc) (void)hipFree(enc);
+    if (own_w && w) (void)hipFree(w);
+    return result;
+#undef MM_PIPE_FAIL
+}
+
+// -----------------------------------------------------------------------------------------
+// Legacy symbols (host pointers).  One process-wide context on device 0 / default stream.
+// -----------------------------------------------------------------------------------------
+static std::mutex g_legacy_mutex;
+static mm_context *g_legacy_ctx = nullptr;
+
+static mm_context *legacy_context()
+{
+    if (!g_legacy_ctx) {
+        if (mm_context_create(0, nullptr, &g_legacy_ctx) != MM_OK) g_legacy_ctx = nullptr;
+    }
+    return g_legacy_ctx;
+}
+
+namespace {
+struct DeviceBuf {
+    void *p = nullptr;
+    ~DeviceBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+};
+
+template <typename T>
+i64 max_plus_one(const T *a, size_t n)
+{
+    T m = -1;
+    for (size_t i = 0; i < n; ++i)
+        if (a[i] > m) m = a[i];
+    return (i64)m + 1;
+}
+}  // namespace
+
+static int legacy_fail(const char *what)
+{
+    fprintf(stderr, "multi_mesh_hip: %s failed: %s\n", what, mm_last_error());
+    return mm_last_status();
+}
+
+extern "C" void centroid(long long ndim, long long nelem, long long nper, long long *connectivity, double *points,
+                         double *centroid_out)
+{
+    std::lock_guard<std::mutex> lock(g_legacy_mutex);
+    mm_clear_status();
+    if (nelem <= 0) return;
+    if (ndim < 1 || ndim > 3 || nper < 1 || !connectivity || !points || !centroid_out) {
+        mm_set_error(MM_ERR_ARG, "centroid: bad argument");
+        (void)legacy_fail("centroid");
+        return;
+    }
+    mm_context *ctx = legacy_context();
+    if (!ctx) {
+        (void)legacy_fail("centroid");
+        return;
+    }
+    const size_t nconn = (size_t)nelem * (size_t)nper;
+    const i64 npoints = max_plus_one(connectivity, nconn);
+    DeviceBuf d_conn, d_pts, d_out;
+    hipError_t e = d_conn.alloc(nconn * sizeof(i64));
+    if (e == hipSuccess) e = d_pts.alloc((size_t)npoints * ndim * sizeof(double));
+    if (e == hipSuccess) e = d_out.alloc((size_t)nelem * ndim * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conn.p, connectivity, nconn * sizeof(i64), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_pts.p, points, (size_t)npoints * ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "centroid: %s", hipGetErrorString(e));
+        (void)legacy_fail("centroid");
+        return;
+    }
+    if (mm_centroid(ctx, ndim, nelem, nper, (const int64_t *)d_conn.p, (const double *)d_pts.p, (double *)d_out.p) != MM_OK) {
+        (void)legacy_fail("centroid");
+        return;
+    }
+    e = hipMemcpyAsync(centroid_out, d_out.p, (size_t)nelem * ndim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "centroid: %s", hipGetErrorString(e));
+        (void)legacy_fail("centroid");
+    }
+}
+
+extern "C" long long triLinearInterpolator(long long k, long long npoints, long long *nn, long long *connectivity,
+                                           long long *enc, double *nodes, double *weights, double *points)
+{
+    std::lock_guard<std::mutex> lock(g_legacy_mutex);
+    mm_clear_status();
+    if (npoints <= 0 || k <= 0) return 0;  // the reference's loops do nothing
+    if (!nn || !connectivity || !enc || !nodes || !weights || !points) {
+        mm_set_error(MM_ERR_ARG, "triLinearInterpolator: null array");
+        return legacy_fail("triLinearInterpolator");
+    }
+    mm_context *ctx = legacy_context();
+    if (!ctx) return legacy_fail("triLinearInterpolator");
+    // sizes the reference signature does not carry
+    const size_t nnn = (size_t)npoints * (size_t)k;
+    for (size_t i = 0; i < nnn; ++i)
+        if (nn[i] < 0) {
+            mm_set_error(MM_ERR_ARG, "triLinearInterpolator: negative element index");
+            return legacy_fail("triLinearInterpolator");
+        }
+    const i64 nelem = max_plus_one(nn, nnn);
+    const i64 nnodes = max_plus_one(connectivity, (size_t)nelem * 8);
+    DeviceBuf d_nn, d_conn, d_enc, d_nodes, d_w, d_pts;
+    hipError_t e = d_nn.alloc(nnn * sizeof(i64));
+    if (e == hipSuccess) e = d_conn.alloc((size_t)nelem * 8 * sizeof(i64));
+    if (e == hipSuccess) e = d_enc.alloc((size_t)npoints * 8 * sizeof(i64));
+    if (e == hipSuccess) e = d_nodes.alloc((size_t)nnodes * 3 * sizeof(double));
+    if (e == hipSuccess) e = d_w.alloc((size_t)npoints * 8 * sizeof(double));
+    if (e == hipSuccess) e = d_pts.alloc((size_t)npoints * 3 * sizeof(double));
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nn.p, nn, nnn * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conn.p, connectivity, (size_t)nelem * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nodes.p, nodes, (size_t)nnodes * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    // in-place contract: rows of failed points keep the caller's contents
+    if (e == hipSuccess) e = hipMemcpyAsync(d_enc.p, enc, (size_t)npoints * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w.p, weights, (size_t)npoints * 8 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "triLinearInterpolator: %s", hipGetErrorString(e));
+        return legacy_fail("triLinearInterpolator");
+    }
+    const int64_t nfailed = mm_locate_hex8(ctx, k, npoints, (const int64_t *)d_nn.p, (const int64_t *)d_conn.p, nelem, 0,
+                                           (int64_t *)d_enc.p, (const double *)d_nodes.p, (double *)d_w.p,
+                                           (const double *)d_pts.p);
+    if (nfailed < 0) return legacy_fail("triLinearInterpolator");
+    e = hipMemcpyAsync(enc, d_enc.p, (size_t)npoints * 8 * sizeof(i64), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w.p, (size_t)npoints * 8 * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "triLinearInterpolator: %s", hipGetErrorString(e));
+        return legacy_fail("triLinearInterpolator");
+    }
+    return nfailed;
+}

@@ -1,0 +1,278 @@
+"""Thin ctypes layer over the device-pointer API of ``multi_mesh_hip.so``.
+
+Arrays handed to a :class:`Context` method may be NumPy arrays (copied to HBM for the call),
+:class:`DeviceArray` objects, or anything exposing ``data_ptr()`` / ``shape`` / ``dtype``
+(``torch`` CUDA tensors -- torch is only plumbing for device memory and RCCL here).  Results
+are :class:`DeviceArray` objects; ``.numpy()`` copies them back.
+
+No CPU fallback: every method ends in a HIP kernel launch and raises
+:class:`multimesh_amd.helpers.MultiMeshHipError` when the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .helpers import MM_KNN_MAX_K, STAGES, MultiMeshHipError, check, load_lib
+
+_NP2ITEM = {np.dtype(np.float64): 8, np.dtype(np.int64): 8, np.dtype(np.int32): 4}
+
+
+class DeviceArray:
+    """A C-contiguous array resident in HBM, owned (or merely viewed) by a Context."""
+
+    def __init__(self, ctx, ptr, shape, dtype, owner=True, keepalive=None):
+        self.ctx = ctx
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner
+        self._keepalive = keepalive
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            check(self.ctx.lib.mm_copy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "mm_copy_d2h")
+        return out
+
+    def rows(self, start, stop):
+        """A non-owning view of rows [start, stop) (first axis)."""
+        row_bytes = self.nbytes // max(self.shape[0], 1) if self.shape[0] else 0
+        return DeviceArray(self.ctx, self.ptr + start * row_bytes, (stop - start,) + self.shape[1:], self.dtype,
+                           owner=False, keepalive=self)
+
+    def free(self):
+        if self._owner and self.ptr and self.ctx.handle:
+            self.ctx.lib.mm_device_free(self.ctx.handle, self.ptr)
+        self.ptr = 0
+        self._owner = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class KnnIndex:
+    """Device-resident search structure over source points (the cKDTree stand-in)."""
+
+    def __init__(self, ctx, handle, nsrc, ndim, keepalive):
+        self.ctx, self.handle, self.nsrc, self.ndim = ctx, handle, nsrc, ndim
+        self._keepalive = keepalive
+
+    def query(self, points, k, want_dist=False):
+        """``tree.query(points, k)`` of reference scripts/cli.py:71-73 -> idx int64[N,k] (, dist)."""
+        ctx = self.ctx
+        pts = ctx.asdevice(points, np.float64)
+        if len(pts.shape) != 2 or pts.shape[1] != self.ndim:
+            raise ValueError("points must be [N, ndim]")
+        if not 0 <= k <= MM_KNN_MAX_K:
+            raise ValueError(f"k must be in 0..{MM_KNN_MAX_K}")
+        n = pts.shape[0]
+        idx = ctx.empty((n, k), np.int64)
+        dist = ctx.empty((n, k), np.float64) if want_dist else None
+        check(ctx.lib.mm_knn_query(ctx.handle, self.handle, pts.ptr, n, k, idx.ptr, dist.ptr if dist else None),
+              "mm_knn_query")
+        return (idx, dist) if want_dist else idx
+
+    def free(self):
+        if self.handle and self.ctx.handle:
+            self.ctx.lib.mm_knn_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream.  ``stream`` is a raw hipStream_t value (e.g.
+    ``torch.cuda.current_stream().cuda_stream``); None = the device's default stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_lib()
+        h = C.c_void_p()
+        check(self.lib.mm_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)),
+              "mm_context_create")
+        self.handle = h.value
+        self.device = int(device)
+
+    # ---- memory -------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        dtype = np.dtype(dtype)
+        p = C.c_void_p()
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        check(self.lib.mm_device_alloc(self.handle, nbytes, C.byref(p)), "mm_device_alloc")
+        return DeviceArray(self, p.value, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = self.empty(shape, dtype)
+        if a.nbytes:
+            check(self.lib.mm_memset(self.handle, a.ptr, 0, a.nbytes), "mm_memset")
+        return a
+
+    def to_device(self, array, dtype=None):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        d = self.empty(a.shape, a.dtype)
+        if a.nbytes:
+            check(self.lib.mm_copy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes), "mm_copy_h2d")
+        return d
+
+    def asdevice(self, x, dtype):
+        """NumPy -> copy to HBM; DeviceArray / torch-like -> wrap without copying."""
+        dtype = np.dtype(dtype)
+        if isinstance(x, DeviceArray):
+            if x.dtype != dtype:
+                raise TypeError(f"expected {dtype}, got {x.dtype}")
+            return x
+        if hasattr(x, "data_ptr") and hasattr(x, "shape"):
+            name = str(getattr(x, "dtype", "")).replace("torch.", "")
+            if name and np.dtype(name) != dtype:
+                raise TypeError(f"expected {dtype}, got {name}")
+            if hasattr(x, "is_contiguous") and not x.is_contiguous():
+                raise ValueError("device tensor must be contiguous")
+            return DeviceArray(self, x.data_ptr(), tuple(x.shape), dtype, owner=False, keepalive=x)
+        return self.to_device(np.asarray(x), dtype)
+
+    def synchronize(self):
+        check(self.lib.mm_synchronize(self.handle), "mm_synchronize")
+
+    # ---- timers -------------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        check(self.lib.mm_set_profiling(self.handle, 1 if on else 0), "mm_set_profiling")
+
+    def last_timings(self):
+        """Per-stage milliseconds of the last call (hipEvents on this context's stream)."""
+        buf = (C.c_double * len(STAGES))()
+        check(self.lib.mm_last_timings(self.handle, buf, len(STAGES)), "mm_last_timings")
+        return {name: buf[i] for i, name in enumerate(STAGES)}
+
+    # ---- A1 -----------------------------------------------------------------------------
+    def centroid(self, connectivity, points):
+        conn = self.asdevice(connectivity, np.int64)
+        pts = self.asdevice(points, np.float64)
+        nelem, nper = conn.shape
+        ndim = pts.shape[1]
+        out = self.empty((nelem, ndim), np.float64)
+        check(self.lib.mm_centroid(self.handle, ndim, nelem, nper, conn.ptr, pts.ptr, out.ptr), "mm_centroid")
+        return out
+
+    # ---- A2 -----------------------------------------------------------------------------
+    def knn_build(self, sources):
+        src = self.asdevice(sources, np.float64)
+        if len(src.shape) != 2 or not 1 <= src.shape[1] <= 3:
+            raise ValueError("sources must be [nsrc, ndim] with ndim in 1..3")
+        h = C.c_void_p()
+        check(self.lib.mm_knn_build(self.handle, src.ptr, src.shape[0], src.shape[1], C.byref(h)), "mm_knn_build")
+        return KnnIndex(self, h.value, src.shape[0], src.shape[1], keepalive=src)
+
+    # ---- A4 -----------------------------------------------------------------------------
+    def locate_hex8(self, nearest_element_indices, connectivity, nodes, points, enc=None, weights=None,
+                    conn_is_exodus=False):
+        """Returns (enc int64[N,8], weights f64[N,8], nfailed).  ``enc``/``weights`` given ->
+        updated in place (rows of failed points untouched), else zero-initialised here as the
+        reference's callers do (scripts/cli.py:77-78)."""
+        nn = self.asdevice(nearest_element_indices, np.int64)
+        conn = self.asdevice(connectivity, np.int64)
+        nod = self.asdevice(nodes, np.float64)
+        pts = self.asdevice(points, np.float64)
+        n = pts.shape[0]
+        k = nn.shape[1] if len(nn.shape) == 2 else 0
+        if conn.shape[1] != 8 or nod.shape[1] != 3 or pts.shape[1] != 3 or nn.shape[0] != n:
+            raise ValueError("shape mismatch: need nn[N,k], connectivity[E,8], nodes[M,3], points[N,3]")
+        enc = self.zeros((n, 8), np.int64) if enc is None else self.asdevice(enc, np.int64)
+        w = self.zeros((n, 8), np.float64) if weights is None else self.asdevice(weights, np.float64)
+        nf = check(self.lib.mm_locate_hex8(self.handle, k, n, nn.ptr, conn.ptr, conn.shape[0],
+                                           1 if conn_is_exodus else 0, enc.ptr, nod.ptr, w.ptr, pts.ptr),
+                   "mm_locate_hex8")
+        return enc, w, int(nf)
+
+    # ---- A9 -----------------------------------------------------------------------------
+    def gather(self, fields, ids, weights, point_major=True):
+        """fields f64[C,M] (or [M]) -> f64[N,C] (point_major) or f64[C,N]."""
+        f = self.asdevice(fields, np.float64)
+        if len(f.shape) == 1:
+            f = DeviceArray(self, f.ptr, (1, f.shape[0]), f.dtype, owner=False, keepalive=f)
+        idv = self.asdevice(ids, np.int64)
+        w = self.asdevice(weights, np.float64)
+        if idv.shape != w.shape or len(idv.shape) != 2:
+            raise ValueError("ids and weights must both be [N, P]")
+        n, p = idv.shape
+        ncomp, nsrc = f.shape
+        out = self.empty((n, ncomp) if point_major else (ncomp, n), np.float64)
+        check(self.lib.mm_gather(self.handle, f.ptr, nsrc, ncomp, idv.ptr, w.ptr, n, p, out.ptr,
+                                 1 if point_major else 0), "mm_gather")
+        return out
+
+    # ---- fused ---------------------------------------------------------------------------
+    def interpolate_hex8(self, nodes, connectivity, points, fields, nelem_to_search=20, want_operator=False,
+                         out=None):
+        """The whole hot path of reference scripts/cli.py:62-100 on resident arrays.
+        connectivity is the mesh's own (exodus-order) hex8 connectivity.
+        Returns (values f64[N,C], nfailed) or (values, enc, weights, nfailed)."""
+        nod = self.asdevice(nodes, np.float64)
+        conn = self.asdevice(connectivity, np.int64)
+        pts = self.asdevice(points, np.float64)
+        f = self.asdevice(fields, np.float64)
+        if len(f.shape) == 1:
+            f = DeviceArray(self, f.ptr, (1, f.shape[0]), f.dtype, owner=False, keepalive=f)
+        n = pts.shape[0]
+        ncomp = f.shape[0]
+        if f.shape[1] != nod.shape[0]:
+            raise ValueError("fields must be [C, number of nodes]")
+        out = self.empty((n, ncomp), np.float64) if out is None else self.asdevice(out, np.float64)
+        enc = self.empty((n, 8), np.int64) if want_operator else None
+        w = self.empty((n, 8), np.float64) if want_operator else None
+        nf = check(self.lib.mm_interpolate_hex8(self.handle, nod.ptr, nod.shape[0], conn.ptr, conn.shape[0],
+                                                pts.ptr, n, f.ptr, ncomp, nelem_to_search, out.ptr,
+                                                enc.ptr if enc else None, w.ptr if w else None),
+                   "mm_interpolate_hex8")
+        if want_operator:
+            return out, enc, w, int(nf)
+        return out, int(nf)
+
+    def close(self):
+        if self.handle:
+            self.lib.mm_context_destroy(self.handle)
+        self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use; raises without a GPU)."""
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+__all__ = ["Context", "DeviceArray", "KnnIndex", "default_context", "MultiMeshHipError"]
