@@ -18,6 +18,7 @@
 // source lies beyond that face).  Cells along z are contiguous in memory, so a block column is
 // one coordinate run.
 #include <math.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -26,7 +27,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr double kTargetPerCell = 4.0;  // average sources per cell
+constexpr double kDefaultPerCell = 8.0;  // average sources per cell: the k = 20 ball (radius ~0.84 cell) fits the 3x3x3 block
 constexpr int kMaxCellsPerAxis = 1024;
 
 struct GridParams {
@@ -247,17 +248,33 @@ struct BestList {
     }
 };
 
-template <int K>
-__global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsrc,
-                                                           const int *__restrict__ cell_start,
-                                                           const double *__restrict__ sorted_xyz,
-                                                           const int *__restrict__ sorted_id,
-                                                           const double *__restrict__ pts, i64 npts, int ndim,
-                                                           int kout, i64 *__restrict__ idx_out,
-                                                           double *__restrict__ dist_out)
+// Lower bound on the distance from the target to any source outside the (2R+1)^3 block of cells
+// around (cx,cy,cz): distance to the nearest block face that still has cells behind it, minus a
+// slack for sources sitting a rounding error outside their cell's nominal box.  +inf when the
+// block covers the whole grid.
+__device__ __forceinline__ double block_bound(const GridParams &g, double px, double py, double pz, int cx,
+                                              int cy, int cz, int R)
 {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npts) return;
+    const double slack_x = 1e-9 * g.hx, slack_y = 1e-9 * g.hy, slack_z = 1e-9 * g.hz;
+    double bound = INFINITY;
+    if (cx - R > 0) bound = fmin(bound, (px - (g.lox + (double)(cx - R) * g.hx)) - slack_x);
+    if (cx + R < g.nx - 1) bound = fmin(bound, ((g.lox + (double)(cx + R + 1) * g.hx) - px) - slack_x);
+    if (cy - R > 0) bound = fmin(bound, (py - (g.loy + (double)(cy - R) * g.hy)) - slack_y);
+    if (cy + R < g.ny - 1) bound = fmin(bound, ((g.loy + (double)(cy + R + 1) * g.hy) - py) - slack_y);
+    if (cz - R > 0) bound = fmin(bound, (pz - (g.loz + (double)(cz - R) * g.hz)) - slack_z);
+    if (cz + R < g.nz - 1) bound = fmin(bound, ((g.loz + (double)(cz + R + 1) * g.hz) - pz) - slack_z);
+    return bound;
+}
+
+// ---- generic path: ring expansion with a register-resident sorted list.  Always correct for any
+// density; used for the stragglers the fast kernel hands over (and for k > 32).
+template <int K>
+__device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, const int *__restrict__ cell_start,
+                                              const double *__restrict__ sorted_xyz,
+                                              const int *__restrict__ sorted_id, const double *__restrict__ pts,
+                                              int ndim, int kout, i64 *__restrict__ idx_out,
+                                              double *__restrict__ dist_out, i64 i)
+{
     const double px = pts[i * ndim];
     const double py = ndim > 1 ? pts[i * ndim + 1] : 0.0;
     const double pz = ndim > 2 ? pts[i * ndim + 2] : 0.0;
@@ -267,9 +284,6 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
 
     BestList<K> best;
     best.init((int)nsrc);
-
-    // slack: a source assigned to cell c may sit this far outside the cell's nominal box
-    const double slack_x = 1e-9 * g.hx, slack_y = 1e-9 * g.hy, slack_z = 1e-9 * g.hz;
 
     int rprev = -1;  // radius already scanned completely
     for (int R = 1;; ++R) {
@@ -314,20 +328,11 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
             }
         }
         rprev = R;
-        // whole grid scanned?
         const bool all_x = (cx - R <= 0) && (cx + R >= g.nx - 1);
         const bool all_y = (cy - R <= 0) && (cy + R >= g.ny - 1);
         const bool all_z = (cz - R <= 0) && (cz + R >= g.nz - 1);
         if (all_x && all_y && all_z) break;
-        // distance from the target to the nearest face of the scanned block that still has
-        // cells behind it; every unscanned source is at least that far away (minus slack)
-        double bound = INFINITY;
-        if (cx - R > 0) bound = fmin(bound, (px - (g.lox + (double)(cx - R) * g.hx)) - slack_x);
-        if (cx + R < g.nx - 1) bound = fmin(bound, ((g.lox + (double)(cx + R + 1) * g.hx) - px) - slack_x);
-        if (cy - R > 0) bound = fmin(bound, (py - (g.loy + (double)(cy - R) * g.hy)) - slack_y);
-        if (cy + R < g.ny - 1) bound = fmin(bound, ((g.loy + (double)(cy + R + 1) * g.hy) - py) - slack_y);
-        if (cz - R > 0) bound = fmin(bound, (pz - (g.loz + (double)(cz - R) * g.hz)) - slack_z);
-        if (cz + R < g.nz - 1) bound = fmin(bound, ((g.loz + (double)(cz + R + 1) * g.hz) - pz) - slack_z);
+        const double bound = block_bound(g, px, py, pz, cx, cy, cz, R);
         // k-th best so far (kout <= K; the list keeps K, the bound needs slot kout-1)
         double kth = best.d[K - 1];
         if (kout < K) {
@@ -347,12 +352,475 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
 }
 
 template <int K>
-void launch_query(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                  int kout, i64 *idx, double *dist)
+__global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsrc,
+                                                           const int *__restrict__ cell_start,
+                                                           const double *__restrict__ sorted_xyz,
+                                                           const int *__restrict__ sorted_id,
+                                                           const double *__restrict__ pts, i64 npts, int ndim,
+                                                           int kout, i64 *__restrict__ idx_out,
+                                                           double *__restrict__ dist_out,
+                                                           const int *__restrict__ list,
+                                                           const int *__restrict__ list_count)
 {
-    const i64 grid = (npts + kBlock - 1) / kBlock;
+    // list != null: only the queued targets (stragglers of the fast kernel), grid-stride
+    const i64 total = list ? (i64)*list_count : npts;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
+        knn_query_one<K>(g, nsrc, cell_start, sorted_xyz, sorted_id, pts, ndim, kout, idx_out, dist_out,
+                         list ? (i64)list[q] : q);
+}
+
+// ---- fast path: one wave per grid cell, sources staged in LDS --------------------------------
+// A wave owns one cell of the search grid and serves every target that falls into it.
+//   stage : the cell's 3x3x3 neighbourhood (9 column runs of the cell-sorted source array) is read
+//           ONCE with coalesced loads and kept in LDS as float4 {x,y,z relative to the cell corner,
+//           position in the sorted array} -- instead of every lane chasing its own candidates
+//           through L1 (~20 cache-line lookups per divergent load).
+//   split : the 64 lanes form groups of S lanes per target (S chosen so that one round covers the
+//           cell's targets, 8 <= S <= 64); lane `sl` of a group handles tile entries sl, sl+S, ...
+//           Lanes of different groups read the same tile address (LDS broadcast).
+//   P1    : fp32 squared distances (fused multiply-adds: this pass is only a filter) binned into a
+//           64-bucket histogram per target (LDS atomics; the bucket range comes from the
+//           neighbourhood's source density); each lane also keeps its candidates' bucket numbers
+//           packed in registers.  jb = first bucket whose running count reaches k.
+//   P2    : every candidate in a bucket <= jb+1 is appended to the target's list -- a superset of
+//           the exact k nearest including exact ties (see the error bound) -- without touching the
+//           distances again.
+//   exact : for the ~k listed candidates only, d2 in fp64 exactly as the reference computes it
+//           (coordinates re-read from the fp64 source array) and the source id.
+//   P3    : rank sort of the list by exact d2 (ties: a second, lexicographic (d2, id) pass that
+//           only runs when two listed distances are bit-equal); rank r < k goes to output slot r.
+// Error bound.  Tile and target coordinates are rounded to fp32 relative to the cell corner O, so a
+// coordinate difference is off by at most u(|s-O| + |p-O|) + u|diff| per axis (u = 2^-24) and the
+// fp32 distance d32 differs from the exact distance d by at most E + 2u*d with
+// E = 3u * sum_axes(|p-O| + 2h).  At least k candidates have a fp32 squared distance below the
+// upper edge e1 of bucket jb, so the exact k-th distance is <= D = sqrt(e1)(1+4u) + E, and every
+// candidate at exact distance <= D has d32 <= D(1+4u) + E.  The kernel checks that this is below
+// the upper edge of bucket jb+1 (true unless the buckets are absurdly narrow), which makes
+// "bucket <= jb+1" a superset of the exact k nearest.
+// A target is handed to the generic kernel (queue) when the neighbourhood holds fewer than k
+// sources, more than the tile or a column run longer than 64, the k-th distance falls outside the
+// histogram range, its list overflows (many exact ties), or the exact k-th distance is not closer
+// than the nearest block face (a nearer source could sit outside the block).
+constexpr int kWave = 64;
+constexpr int kHistBuckets = 64;
+constexpr int kTileCap = 256;       // sources per tile (27 cells x ~8 expected)
+constexpr int kMaxGroups = 8;       // targets per round at the narrowest split (S = 8)
+constexpr int kSlots = kTileCap / kMaxGroups;  // tile entries per lane at the narrowest split
+
+// inclusive prefix sum inside groups of S consecutive lanes (S a power of two)
+__device__ __forceinline__ int group_scan(int v, int sl, int S)
+{
+    for (int d = 1; d < S; d <<= 1) {
+        const int t = __shfl_up(v, d, S);
+        if (sl >= d) v += t;
+    }
+    return v;
+}
+
+// The fast kernel's workgroup is ONE wave: its LDS accesses are served in program order by the LDS
+// queue, so a later read sees an earlier write/atomic of any lane without waiting or s_barrier.  All
+// that is needed is to keep the COMPILER from moving LDS accesses across the hand-over points.
+// (__syncthreads() would also drain every outstanding global load -- s_waitcnt vmcnt(0) -- at each
+// of the seven points per round, exposing the full memory latency each time.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int K, int CAP>
+__global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 nsrc,
+                                                            const int *__restrict__ cell_start,
+                                                            const double *__restrict__ sorted_xyz,
+                                                            const int *__restrict__ sorted_id,
+                                                            const double *__restrict__ pts, int ndim, int kout,
+                                                            const int *__restrict__ tstart,
+                                                            const int *__restrict__ perm,
+                                                            const double *__restrict__ tsorted,
+                                                            i64 *__restrict__ idx_out,
+                                                            double *__restrict__ dist_out,
+                                                            int *__restrict__ fb_list, int *__restrict__ fb_count,
+                                                            int dbg_stop)
+{
+    static_assert(CAP <= 64, "rank mask is 64 bits");
+    __shared__ float4 tile[kTileCap];
+    __shared__ double s_bd[CAP][kMaxGroups];
+    __shared__ int s_bx[CAP][kMaxGroups];                       // source position, then source id
+    __shared__ unsigned s_hist[kHistBuckets + 1][kMaxGroups];   // last row: sink for idle lanes
+    __shared__ int s_jb[kMaxGroups];
+    __shared__ int s_cnt[kMaxGroups];
+    __shared__ unsigned long long s_seen[kMaxGroups];
+
+    const int lane = threadIdx.x;
+    // grid = (nz, ny, nx): the cell's coordinates come straight from the block index
+    const int cz = blockIdx.x, cy = blockIdx.y, cx = blockIdx.z;
+    const int cell = (cx * g.ny + cy) * g.nz + cz;
+
+    // metadata: the cell's target range and the 9 column runs of its neighbourhood, all loads
+    // issued together (every address depends on the block index only)
+    const int t0 = tstart[cell];
+    const int t1 = tstart[cell + 1];
+    const int za = max(cz - 1, 0), zb = min(cz + 1, g.nz - 1);
+    int rs[9], rl[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int ix = cx + (c / 3) - 1, iy = cy + (c % 3) - 1;
+        const bool inside = (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny;
+        const int col = inside ? (ix * g.ny + iy) * g.nz : 0;
+        const int s0 = cell_start[col + za];
+        const int s1 = cell_start[col + zb + 1];
+        rs[c] = inside ? s0 : 0;
+        rl[c] = inside ? s1 - s0 : 0;
+    }
+    const int tn = t1 - t0;
+    if (tn == 0) return;
+    if (dbg_stop == 6) return;
+    int total = 0;
+    bool runs_fit = true;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        total += rl[c];
+        runs_fit = runs_fit && rl[c] <= kWave;
+    }
+    const double ox = g.lox + (double)cx * g.hx;
+    const double oy = g.loy + (double)cy * g.hy;
+    const double oz = g.loz + (double)cz * g.hz;
+
+    // histogram range from the local density: the ball holding k of the block's `total` sources
+    // has r^d = (k/total) * V_block / c_d; buckets are uniform in r^2 over [0, 2.2 r^2).  Only a
+    // heuristic range, so fast exp2/log2 are fine.
+    float scale;
+    {
+        const int bx = min(cx + 1, g.nx - 1) - max(cx - 1, 0) + 1;
+        const int by = min(cy + 1, g.ny - 1) - max(cy - 1, 0) + 1;
+        const int bz = zb - za + 1;
+        int d = 0;
+        float vol = 1.f;
+        if (g.nx > 1) { ++d; vol *= (float)bx * (float)g.hx; }
+        if (g.ny > 1) { ++d; vol *= (float)by * (float)g.hy; }
+        if (g.nz > 1) { ++d; vol *= (float)bz * (float)g.hz; }
+        const float frac = (float)kout / (float)max(total, 1);
+        float r2;
+        if (d == 3) r2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(frac * vol * (1.f / 4.18879f)) * (2.f / 3.f));
+        else if (d == 2) r2 = frac * vol * (1.f / 3.14159f);
+        else if (d == 1) { const float r = frac * vol * 0.5f; r2 = r * r; }
+        else r2 = 1.f;
+        scale = (float)kHistBuckets / (2.2f * r2);
+    }
+    const bool cell_ok = runs_fit && total >= kout && total <= kTileCap && scale > 0.f && scale < INFINITY;
+    if (dbg_stop == 7) { if (total == 12345 && scale == 1.f) fb_list[0] = 1; return; }
+    if (!cell_ok) {
+        // the whole cell goes to the generic kernel
+        for (int q = lane; q < tn; q += kWave) fb_list[atomicAdd(fb_count, 1)] = perm[t0 + q];
+        return;
+    }
+
+    // lanes per target: the widest split whose round still covers all of the cell's targets
+    int S = kWave;
+    while (S > kWave / kMaxGroups && kWave / S < tn) S >>= 1;
+    const int tpw = kWave / S;       // targets per round
+    const int tg = lane / S;         // this lane's target slot in the round
+    const int sl = lane % S;         // this lane's slice of the tile
+    constexpr int U = 4;
+    constexpr double kU = 0x1p-24;
+    const int nbatch = (total + U * S - 1) / (U * S);
+    const int bpl = kHistBuckets / S;  // histogram buckets per lane in the scan (S = 64 -> 1)
+
+    // first round's targets: cell-sorted copies of the coordinates (contiguous, no indirection);
+    // issued before the tile loads so that both are in flight together
+    double npx, npy, npz;
+    {
+        const bool v = tg < tn;
+        const i64 q = (i64)(t0 + (v ? tg : 0)) * 3;
+        npx = tsorted[q + 0];
+        npy = tsorted[q + 1];
+        npz = tsorted[q + 2];
+    }
+
+    // ---- stage the tile: every run holds at most 64 sources, so lane l fetches source l of each
+    // run (three runs' loads in flight at a time keeps the register footprint small)
+    {
+        int off = 0;
+#pragma unroll
+        for (int c3 = 0; c3 < 9; c3 += 3) {
+            double sx[3], sy[3], sz[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const i64 s = (i64)rs[c3 + c] + min(lane, max(rl[c3 + c] - 1, 0));
+                sx[c] = sorted_xyz[s * 3 + 0];
+                sy[c] = sorted_xyz[s * 3 + 1];
+                sz[c] = sorted_xyz[s * 3 + 2];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (lane < rl[c3 + c])
+                    tile[off + lane] = make_float4((float)(sx[c] - ox), (float)(sy[c] - oy), (float)(sz[c] - oz),
+                                                   __int_as_float(rs[c3 + c] + lane));
+                off += rl[c3 + c];
+            }
+        }
+    }
+    if (dbg_stop == 1) return;  // diagnostic builds only (MM_KNN_DBG_STOP): time the phases
+
+    for (int r0 = 0; r0 < tn; r0 += tpw) {
+        const int tt = r0 + tg;
+        const bool valid = tt < tn;
+        const i64 i = valid && dbg_stop != 23 ? (i64)perm[t0 + tt] : 0;  // only needed for the output row
+        const double px = valid ? npx : ox;
+        const double py = valid ? npy : oy;
+        const double pz = valid ? npz : oz;
+        if (r0 + tpw < tn) {
+            // next round's targets, in flight during this round
+            const bool v = tt + tpw < tn;
+            const i64 q = (i64)(t0 + (v ? tt + tpw : 0)) * 3;
+            npx = tsorted[q + 0];
+            npy = tsorted[q + 1];
+            npz = tsorted[q + 2];
+        }
+        const float tx = (float)(px - ox), ty = (float)(py - oy), tz = (float)(pz - oz);
+        const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy + g.hz));
+
+        if (dbg_stop != 22) for (int q = lane; q < (kHistBuckets + 1) * kMaxGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
+        if (lane < kMaxGroups) {
+            s_jb[lane] = kHistBuckets;
+            s_seen[lane] = 0ull;
+        }
+        wave_sync();  // tile staged (first round), counters cleared
+
+        // ---- P1: histogram of fp32 squared distances; bucket numbers packed 4 per register
+        unsigned pk[kSlots / U];
+#pragma unroll
+        for (int m = 0; m < kSlots / U; ++m) {
+            pk[m] = 0xffffffffu;
+            if (m < nbatch) {
+                float4 q4[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) q4[u] = dbg_stop == 21 ? make_float4(tx + u, ty + m, tz, 0.f) : tile[min(sl + (m * U + u) * S, total - 1)];
+                unsigned packed = 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float fx = q4[u].x - tx, fy = q4[u].y - ty, fz = q4[u].z - tz;
+                    const float a = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                    const bool live = valid && sl + (m * U + u) * S < total;
+                    // NaN -> last bucket (fminf returns the non-NaN operand).  The last bucket means
+                    // "beyond the histogram range": most candidates land there, and counting them
+                    // would serialise the LDS atomic on one address, so they are not counted.
+                    const int b = (int)fminf(a * scale, (float)(kHistBuckets - 1));
+                    if (live && b < kHistBuckets - 1 && dbg_stop != 20) atomicAdd(&s_hist[b][tg], 1u);
+                    packed |= (live ? (unsigned)b : 0xffu) << (8 * u);
+                }
+                pk[m] = packed;
+            }
+        }
+        wave_sync();
+        if (dbg_stop == 2 || (dbg_stop >= 20 && dbg_stop <= 23)) return;
+
+        // ---- jb = first bucket whose running count reaches k: each lane sums its share of the
+        // buckets, a group prefix sum locates the lane whose share crosses k
+        {
+            int mine = 0;
+            for (int q = 0; q < bpl; ++q) mine += (int)s_hist[sl * bpl + q][tg];
+            const int incl = group_scan(mine, sl, S);
+            int run_count = incl - mine;
+            if (run_count < kout && incl >= kout) {
+                for (int q = 0; q < bpl; ++q) {
+                    run_count += (int)s_hist[sl * bpl + q][tg];
+                    if (run_count >= kout) {
+                        s_jb[tg] = sl * bpl + q;
+                        break;
+                    }
+                }
+            }
+        }
+        wave_sync();
+        const int jb = s_jb[tg];
+        bool hand_over = jb >= kHistBuckets - 2;  // k-th distance beyond the histogram range
+        {
+            // every exact k-nearest candidate must land in a bucket <= jb+1 (header comment)
+            const double e1 = (double)(jb + 1) / (double)scale;
+            const double e2 = (double)(jb + 2) / (double)scale;
+            const double D = sqrt(e1) * (1.0 + 4.0 * kU) + E;
+            const double D2 = D * (1.0 + 4.0 * kU) + E;
+            if (!(D2 * D2 * (1.0 + 8.0 * kU) < e2)) hand_over = true;
+        }
+        if (dbg_stop == 3) { if (jb == 77) fb_list[0] = jb; return; }
+
+        // ---- P2: candidates in buckets <= jb+1 go to the target's list.  Each lane marks its
+        // qualifying slots in a bit mask; a group prefix sum of the counts gives the list offsets.
+        unsigned qmask = 0u;
+#pragma unroll
+        for (int m = 0; m < kSlots / U; ++m) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = (int)((pk[m] >> (8 * u)) & 0xffu);
+                qmask |= (b <= jb + 1 ? 1u : 0u) << (m * U + u);
+            }
+        }
+        if (hand_over) qmask = 0u;
+        const int mycnt = __popc(qmask);
+        const int incl = group_scan(mycnt, sl, S);
+        const int n = __shfl(incl, tg * S + S - 1);
+        int pos = incl - mycnt;
+        while (qmask) {
+            const int slot = __ffs(qmask) - 1;
+            qmask &= qmask - 1u;
+            if (pos < CAP) s_bx[pos][tg] = __float_as_int(tile[sl + slot * S].w);
+            ++pos;
+        }
+        if (sl == 0) s_cnt[tg] = n;
+        wave_sync();
+        if (dbg_stop == 4) return;
+        if (n > CAP) hand_over = true;
+        // widest list in this round (uniform loop bounds below)
+        int nmax = 0;
+        for (int q = 0; q < tpw; ++q) nmax = max(nmax, min(s_cnt[q], CAP));
+        const int owned = (nmax + S - 1) / S;  // list entries per lane: sl, sl+S, ...
+
+        // ---- exact fp64 distance (reference arithmetic) and source id of the owned entries
+        constexpr int MAXE = (CAP + 7) / 8;  // owned entries per lane at the narrowest split
+        double ed[MAXE];
+        int ei[MAXE], rank[MAXE];
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            const bool live = o < owned && e < n && e < CAP;
+            ed[o] = INFINITY;
+            ei[o] = 0x7fffffff;
+            rank[o] = 0;
+            if (live) {
+                const i64 s = (i64)s_bx[e][tg];
+                const double dx = sorted_xyz[s * 3 + 0] - px;
+                const double dy = sorted_xyz[s * 3 + 1] - py;
+                const double dz = sorted_xyz[s * 3 + 2] - pz;
+                double d2 = dx * dx;
+                d2 = d2 + dy * dy;
+                if (ndim > 2) d2 = d2 + dz * dz;
+                ed[o] = d2;
+                ei[o] = sorted_id[s];
+                s_bd[e][tg] = d2;
+                s_bx[e][tg] = ei[o];
+            }
+        }
+        wave_sync();
+        if (dbg_stop == 5) return;
+
+        // ---- P3: rank by exact d2: list entries are read four at a time (broadcast within the
+        // group) and compared against the owned ones
+        for (int j0 = 0; j0 < nmax; j0 += U) {
+            double dj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[min(j0 + u, CAP - 1)][tg] : INFINITY;
+#pragma unroll
+            for (int o = 0; o < MAXE; ++o) {
+                if (o < owned) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) rank[o] += dj[u] < ed[o] ? 1 : 0;
+                }
+            }
+        }
+        if (dbg_stop == 8) return;
+        // distinct distances <=> the ranks are a permutation of 0..n-1
+        const unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            if (o < owned && e < n && e < CAP) atomicOr(&s_seen[tg], 1ull << rank[o]);
+        }
+        wave_sync();
+        const bool tied = valid && !hand_over && s_seen[tg] != full;
+        if (__any(tied)) {
+            // bit-equal distances somewhere in this round: redo the ranks lexicographically
+#pragma unroll
+            for (int o = 0; o < MAXE; ++o) rank[o] = 0;
+            for (int j = 0; j < nmax; ++j) {
+                const bool live = j < n;
+                const double dj = live ? s_bd[min(j, CAP - 1)][tg] : INFINITY;
+                const int ij = live ? s_bx[min(j, CAP - 1)][tg] : 0x7fffffff;
+#pragma unroll
+                for (int o = 0; o < MAXE; ++o)
+                    if (o < owned) rank[o] += before(dj, ij, ed[o], ei[o]) ? 1 : 0;
+            }
+            wave_sync();
+        }
+        if (dbg_stop == 9) return;
+        // sorted order back into the list (every lane has finished reading it)
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            if (o < owned && e < n && e < CAP) {
+                s_bd[rank[o]][tg] = ed[o];
+                s_bx[rank[o]][tg] = ei[o];
+            }
+        }
+        wave_sync();
+        if (dbg_stop == 10) return;
+        if (valid && !hand_over) {
+            // the group's lanes write the target's row side by side (coalesced 8-byte stores)
+            i64 *row = idx_out + i * kout;
+            double *drow = dist_out ? dist_out + i * kout : nullptr;
+            for (int e = sl; e < kout; e += S) {
+                row[e] = (i64)s_bx[e][tg];
+                if (drow) drow[e] = sqrt(s_bd[e][tg]);
+            }
+        }
+        if (dbg_stop == 11) return;
+        if (valid && sl == 0) {
+            if (!hand_over) {
+                // could a nearer source sit outside the 3x3x3 block?
+                const bool all_x = (cx - 1 <= 0) && (cx + 1 >= g.nx - 1);
+                const bool all_y = (cy - 1 <= 0) && (cy + 1 >= g.ny - 1);
+                const bool all_z = (cz - 1 <= 0) && (cz + 1 >= g.nz - 1);
+                if (!(all_x && all_y && all_z)) {
+                    const double kth = s_bd[kout - 1][tg];
+                    const double bound = block_bound(g, px, py, pz, cx, cy, cz, 1);
+                    if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
+                }
+            }
+            if (hand_over) fb_list[atomicAdd(fb_count, 1)] = (int)i;
+        }
+        wave_sync();  // before the next round clears the counters
+    }
+}
+
+// targets -> visiting order (counting sort by cell, same machinery as the source sort)
+__global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int *__restrict__ cell_of, i64 npts,
+                                                                const double *__restrict__ pts, int ndim,
+                                                                int *__restrict__ cursor, int *__restrict__ perm,
+                                                                double *__restrict__ tsorted)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts) return;
+    const int pos = atomicAdd(&cursor[cell_of[t]], 1);
+    perm[pos] = (int)t;
+    tsorted[(i64)pos * 3 + 0] = pts[t * ndim];
+    tsorted[(i64)pos * 3 + 1] = ndim > 1 ? pts[t * ndim + 1] : 0.0;
+    tsorted[(i64)pos * 3 + 2] = ndim > 2 ? pts[t * ndim + 2] : 0.0;
+}
+
+template <int K>
+void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
+                    int kout, i64 *idx, double *dist, const int *list, const int *list_count)
+{
+    i64 grid = (npts + kBlock - 1) / kBlock;
+    if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
     hipLaunchKernelGGL((knn_query_kernel<K>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
-                       ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, npts, ix->ndim, kout, idx, dist);
+                       ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, npts, ix->ndim, kout, idx, dist, list,
+                       list_count);
+}
+
+template <int K>
+void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
+                 int kout, const int *tstart, const int *perm, const double *tsorted, i64 *idx, double *dist,
+                 int *fb_list, int *fb_count)
+{
+    constexpr int CAP = K + 12;
+    static const int dbg_stop = getenv("MM_KNN_DBG_STOP") ? atoi(getenv("MM_KNN_DBG_STOP")) : 0;
+    hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3(ix->dims[2], ix->dims[1], ix->dims[0]), dim3(kWave), 0, ctx->stream, g,
+                       ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, ix->ndim, kout, tstart, perm,
+                       tsorted, idx, dist, fb_list, fb_count, dbg_stop);
+    launch_generic<K>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
 
 GridParams params_of(const mm_knn_index *ix)
@@ -415,7 +883,13 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
             return MM_ERR_HIP;
         }
     }
-    // grid resolution: ~kTargetPerCell sources per cell over the axes that have extent
+    // grid resolution: ~per_cell sources per cell over the axes that have extent
+    // (MM_KNN_PER_CELL overrides the default, for tuning experiments only)
+    double per_cell = kDefaultPerCell;
+    if (const char *env = getenv("MM_KNN_PER_CELL")) {
+        const double v = atof(env);
+        if (v >= 0.25 && v <= 4096.0) per_cell = v;
+    }
     double ext[3] = {0, 0, 0};
     int live = 0;
     double vol = 1.0;
@@ -427,7 +901,7 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
             vol *= ext[a];
         }
     }
-    const double want_cells = nsrc > 0 ? (double)nsrc / kTargetPerCell : 1.0;
+    const double want_cells = nsrc > 0 ? (double)nsrc / per_cell : 1.0;
     const double edge = live > 0 ? pow(vol / (want_cells > 1.0 ? want_cells : 1.0), 1.0 / live) : 1.0;
     i64 ncells = 1;
     for (int a = 0; a < 3; ++a) {
@@ -495,18 +969,58 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
                       double *dist_d)
 {
     if (npts == 0 || k == 0) return MM_OK;
+    MM_REQUIRE(npts < (i64)0x7fffffff, "too many targets for one query");
     const GridParams g = params_of(ix);
     const int kout = (int)k;
-    if (k <= 1) launch_query<1>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 2) launch_query<2>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 4) launch_query<4>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 8) launch_query<8>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 16) launch_query<16>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 20) launch_query<20>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 25) launch_query<25>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 30) launch_query<30>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else if (k <= 40) launch_query<40>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
-    else launch_query<MM_KNN_MAX_K>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d);
+    if (k > 32) {
+        // long lists: generic ring-expansion kernel for every target
+        if (k <= 40) launch_generic<40>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        else launch_generic<MM_KNN_MAX_K>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        MM_HIP_CHECK(hipGetLastError());
+        return MM_OK;
+    }
+    // scratch: visiting order of the targets (counting sort by cell) + straggler queue
+    const i64 ncells = ix->ncells;
+    const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
+    const size_t need = 3 * mm_round256((size_t)npts * sizeof(int)) +           // cell_of, perm, fb_list
+                        mm_round256((size_t)npts * 3 * sizeof(double)) +        // cell-sorted target coordinates
+                        3 * mm_round256((size_t)(ncells + 1) * sizeof(int)) +   // counts, start, cursor
+                        mm_round256((size_t)ntiles * sizeof(int)) + 1024;
+    int rc = mm_scratch_begin(ctx, need);
+    if (rc != MM_OK) return rc;
+    int *cell_of = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int *perm = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+    int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+    int *cursor = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+    int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
+    int *fb_count = (int *)mm_scratch_take(ctx, 256);
+    double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * 3 * sizeof(double));
+    if (!tsorted || !cell_of || !perm || !fb_list || !counts || !start || !cursor || !tile_sums || !fb_count) {
+        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+        return MM_ERR_ALLOC;
+    }
+    MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
+    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), ctx->stream));
+    const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, ix->ndim, g, cell_of,
+                       counts);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start,
+                       cursor);
+    hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, ix->ndim,
+                       cursor, perm, tsorted);
+
+    if (k <= 1) launch_fast<1>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 2) launch_fast<2>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 4) launch_fast<4>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 8) launch_fast<8>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 16) launch_fast<16>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 20) launch_fast<20>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 25) launch_fast<25>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else launch_fast<32>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }
