@@ -37,10 +37,25 @@ struct mm_scratch {
     size_t used = 0;
 };
 
+// Grow-only device buffers the fused pipeline reuses from call to call (hipMalloc/hipFree of
+// gigabyte-sized intermediates would otherwise cost milliseconds and a device sync per call).
+enum mm_buffer_slot {
+    MM_BUF_CENTROID = 0,
+    MM_BUF_NN,
+    MM_BUF_ENC,
+    MM_BUF_W,
+    MM_BUF_CELL_START,
+    MM_BUF_SORTED_XYZ,
+    MM_BUF_SORTED_ID,
+    MM_BUF_COUNT
+};
+
 struct mm_context {
     int device = 0;
     hipStream_t stream = nullptr;
     mm_scratch scratch;
+    void *buf_ptr[MM_BUF_COUNT] = {};
+    size_t buf_cap[MM_BUF_COUNT] = {};
     // failed-point counter + small readback area (device) and its pinned host mirror
     i64 *d_counters = nullptr;
     i64 *h_counters = nullptr;
@@ -57,6 +72,9 @@ struct mm_context {
 int mm_scratch_begin(mm_context *ctx, size_t total);
 void *mm_scratch_take(mm_context *ctx, size_t bytes);
 static inline size_t mm_round256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Cached buffer of at least `bytes` for `slot` (grows by reallocation, after a stream sync).
+int mm_buffer_get(mm_context *ctx, int slot, size_t bytes, void **out);
 
 // Stage timing helpers: no-ops unless profiling is on.
 void mm_stage_reset(mm_context *ctx);
@@ -84,4 +102,5 @@ struct mm_knn_index {
     int *cell_start = nullptr;     // [ncells + 1] exclusive prefix of per-cell counts
     double *sorted_xyz = nullptr;  // [nsrc][3] source coordinates in cell order (z padded 0)
     int *sorted_id = nullptr;      // [nsrc] original index of each sorted source
+    bool borrowed = false;         // arrays belong to the context's buffer cache (fused pipeline)
 };

@@ -67,6 +67,8 @@ extern "C" void mm_context_destroy(mm_context *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+    for (int s = 0; s < MM_BUF_COUNT; ++s)
+        if (ctx->buf_ptr[s]) (void)hipFree(ctx->buf_ptr[s]);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev_created)
@@ -170,6 +172,27 @@ void *mm_scratch_take(mm_context *ctx, size_t bytes)
     void *p = ctx->scratch.base + ctx->scratch.used;
     ctx->scratch.used += bytes;
     return p;
+}
+
+int mm_buffer_get(mm_context *ctx, int slot, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 256;
+    if (bytes > ctx->buf_cap[slot]) {
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->buf_ptr[slot]) MM_HIP_CHECK(hipFree(ctx->buf_ptr[slot]));
+        ctx->buf_ptr[slot] = nullptr;
+        ctx->buf_cap[slot] = 0;
+        const size_t want = mm_round256(bytes + bytes / 16);
+        hipError_t e = hipMalloc(&ctx->buf_ptr[slot], want);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_ALLOC, "hipMalloc(%zu) for pipeline buffer %d failed: %s", want, slot,
+                         hipGetErrorString(e));
+            return MM_ERR_ALLOC;
+        }
+        ctx->buf_cap[slot] = want;
+    }
+    *out = ctx->buf_ptr[slot];
+    return MM_OK;
 }
 
 // ---- stage timers ------------------------------------------------------------------

@@ -78,16 +78,21 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const double *__re
     }
 }
 
-__global__ void bbox_final_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out)
+__global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
+                                                         double *__restrict__ out)
 {
-    if (threadIdx.x < 6) {
-        const int a = threadIdx.x;
-        double v = partial[a];
-        for (int b = 1; b < nblocks; ++b) {
+    // one wave: lanes stride over the per-block partials, then a butterfly reduction
+    for (int a = 0; a < 6; ++a) {
+        double v = a < 3 ? INFINITY : -INFINITY;
+        for (int b = threadIdx.x; b < nblocks; b += 64) {
             const double p = partial[b * 6 + a];
             v = a < 3 ? fmin(v, p) : fmax(v, p);
         }
-        out[a] = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(v, off);
+            v = a < 3 ? fmin(v, o) : fmax(v, o);
+        }
+        if (threadIdx.x == 0) out[a] = v;
     }
 }
 
@@ -844,16 +849,19 @@ GridParams params_of(const mm_knn_index *ix)
 void free_index(mm_knn_index *ix)
 {
     if (!ix) return;
-    if (ix->cell_start) (void)hipFree(ix->cell_start);
-    if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
-    if (ix->sorted_id) (void)hipFree(ix->sorted_id);
+    if (!ix->borrowed) {
+        if (ix->cell_start) (void)hipFree(ix->cell_start);
+        if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
+        if (ix->sorted_id) (void)hipFree(ix->sorted_id);
+    }
     delete ix;
 }
 
 }  // namespace
 
 // Build without touching the stage timers (used by the fused pipeline too).
-int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out)
+int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
+                      bool use_context_buffers)
 {
     *out = nullptr;
     mm_knn_index *ix = new (std::nothrow) mm_knn_index();
@@ -919,13 +927,30 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     ix->ncells = ncells;
     const GridParams g = params_of(ix);
 
-    hipError_t e = hipMalloc((void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->sorted_id, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
-    if (e != hipSuccess) {
-        mm_set_error(MM_ERR_ALLOC, "kNN index allocation failed: %s", hipGetErrorString(e));
-        free_index(ix);
-        return MM_ERR_ALLOC;
+    hipError_t e = hipSuccess;
+    if (use_context_buffers) {
+        ix->borrowed = true;
+        int brc = mm_buffer_get(ctx, MM_BUF_CELL_START, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
+        if (brc == MM_OK)
+            brc = mm_buffer_get(ctx, MM_BUF_SORTED_XYZ, (size_t)(nsrc > 0 ? nsrc : 1) * 3 * sizeof(double),
+                                (void **)&ix->sorted_xyz);
+        if (brc == MM_OK)
+            brc = mm_buffer_get(ctx, MM_BUF_SORTED_ID, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int),
+                                (void **)&ix->sorted_id);
+        if (brc != MM_OK) {
+            free_index(ix);
+            return brc;
+        }
+    } else {
+        e = hipMalloc((void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * 3 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&ix->sorted_id, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_ALLOC, "kNN index allocation failed: %s", hipGetErrorString(e));
+            free_index(ix);
+            return MM_ERR_ALLOC;
+        }
     }
     const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
     size_t need = mm_round256((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int)) +     // cell_of
@@ -1034,7 +1059,7 @@ extern "C" int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, 
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out);
+    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out, false);
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     return rc;
 }

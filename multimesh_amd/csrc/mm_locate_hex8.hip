@@ -14,6 +14,20 @@
 // Every floating-point expression keeps the reference's association order and the file is built
 // with -ffp-contract=off, so node ids AND weights are bit-identical to the reference.
 //
+// Scheduling.  Walking the candidates in lockstep makes every wave pay for its unluckiest lane
+// in every round (only ~70 % of mesh-node targets are accepted at the nearest centroid, and a
+// diverging Newton runs to the 50-iteration cap).  So the work is done in compacting PASSES: a
+// pass performs at most one Newton solve per still-open target, then re-queues the unresolved
+// targets densely for the next pass.  Before a solve a lane skips candidates whose corner
+// bounding box (x and y only, widened by 5 %) cannot contain the point: such a candidate can
+// never be ACCEPTED -- acceptance needs max|xi| < 1.025 and converged x/y residuals, and the
+// trilinear image of [-1.025,1.025]^3 stays within 3*0.025*(1.025^2/2) = 3.94 % of the corner
+// extent outside the corner bounding box (z is excluded because the reference never tests the z
+// residual).  Skipping is therefore invisible whenever some candidate is accepted.  A target that
+// runs out of candidates without an acceptance (so the reference's "least outside" fallback or a
+// failure is due), or whose solve needs more than 10 iterations, is handed to the reference-order
+// kernel below, which redoes it from scratch.
+//
 // HBM-bound by the roofline accounting (568 B/target when the first candidate is accepted:
 // 24 point + 8k candidates + 64 connectivity row + 192 corner coordinates + 128 out), though
 // the lane spends most of its time in the dependent Newton chain; corner gathers hit L2.
@@ -42,6 +56,7 @@ __device__ __forceinline__ double map_axis(const double (&v)[8], double hr, doub
 
 // Newton inversion (trilinearinterpolator.c:260-305).  x/y/z hold the corner coordinates per
 // axis.  Returns true when converged; xi receives the last iterate either way.
+template <int MAX_IT = 50>
 __device__ __forceinline__ bool newton_hex8(const double px, const double py, const double pz,
                                             const double (&x)[8], const double (&y)[8],
                                             const double (&z)[8], double (&xi)[3])
@@ -55,7 +70,7 @@ __device__ __forceinline__ bool newton_hex8(const double px, const double py, co
     const double sxy = sx > sy ? sx : sy;
     const double scale = sz > sxy ? sz : sxy;
     const double tol = 1e-8 * scale;
-    for (int it = 0; it < 50; ++it) {
+    for (int it = 0; it < MAX_IT; ++it) {
         const double hr = 0.5 * (xi[0] + 1.0);
         const double hs = 0.5 * (xi[1] + 1.0);
         const double ht = 0.5 * (xi[2] + 1.0);
@@ -203,9 +218,19 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                                                           const double *__restrict__ nodes,
                                                           double *__restrict__ w,
                                                           const double *__restrict__ pts,
-                                                          unsigned long long *__restrict__ nfailed)
+                                                          unsigned long long *__restrict__ nfailed,
+                                                          const int *__restrict__ list,
+                                                          const int *__restrict__ list_count)
 {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    // list != null: only the queued targets (left over by the fast passes), grid-stride
+    const i64 total = list ? (i64)*list_count : npoints;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 q0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    // every lane of a wave runs the same number of trips so that the ballot below is wave-wide
+    const i64 trips = (total + stride - 1) / stride;
+    for (i64 trip = 0; trip < trips; ++trip) {
+    const i64 q = q0 + trip * stride;
+    const i64 i = q < total ? (list ? (i64)list[q] : q) : npoints;
     bool failed = false;
     if (i < npoints && k > 0) {
         const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
@@ -246,26 +271,160 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
     }
     const unsigned long long mask = __ballot(failed);
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nfailed, (unsigned long long)__popcll(mask));
+    }
+}
+
+constexpr int kPassIters = 10;
+
+// One compacting pass (see "Scheduling" in the header comment).  q_in == null: the open set is
+// every target, starting at candidate 0.
+template <bool EXODUS>
+__global__ __launch_bounds__(256) void locate_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+                                                          const i64 *__restrict__ conn, i64 nelem,
+                                                          i64 *__restrict__ enc, const double *__restrict__ nodes,
+                                                          double *__restrict__ w, const double *__restrict__ pts,
+                                                          const int2 *__restrict__ q_in,
+                                                          const int *__restrict__ q_in_count,
+                                                          int2 *__restrict__ q_out, int *__restrict__ q_out_count,
+                                                          int *__restrict__ slow_list, int *__restrict__ slow_count)
+{
+    const i64 total = q_in ? (i64)*q_in_count : npoints;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        i64 i;
+        int j;
+        if (q_in) {
+            const int2 e = q_in[q];
+            i = e.x;
+            j = e.y;
+        } else {
+            i = q;
+            j = 0;
+        }
+        const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+        Corners c;
+        // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point
+        bool have = false;
+        for (; j < k; ++j) {
+            const i64 elem = nn[i * k + j];
+            if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
+            load_corners<EXODUS>(conn, nodes, elem, c);
+            double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
+#pragma unroll
+            for (int n = 1; n < 8; ++n) {
+                xlo = fmin(xlo, c.x[n]);
+                xhi = fmax(xhi, c.x[n]);
+                ylo = fmin(ylo, c.y[n]);
+                yhi = fmax(yhi, c.y[n]);
+            }
+            const double mx = 0.05 * (xhi - xlo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+            const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+            // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
+            const bool outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
+            if (!outside) {
+                have = true;
+                break;
+            }
+        }
+        if (!have) {
+            // no candidate left that could be accepted: fallback / failure is the reference's call
+            slow_list[atomicAdd(slow_count, 1)] = (int)i;
+            continue;
+        }
+        double xi[3], wt[8];
+        bool accepted = false;
+        // A solve that has not converged within kPassIters iterations (p99 is 6) would hold the
+        // whole wave for up to 50: such a target is handed to the reference-order kernel instead,
+        // where slow solves only keep each other company.
+        const bool converged = newton_hex8<kPassIters>(px, py, pz, c.x, c.y, c.z, xi);
+        if (converged && in_hull(xi)) {
+            if (max_abs3(xi) < (1 + 0.025)) {
+                weights_hex8(xi, wt);
+                store_row(enc, w, i, c, wt);
+                accepted = true;
+            }
+        }
+        if (!accepted) {
+            if (converged && j + 1 < k) q_out[atomicAdd(q_out_count, 1)] = make_int2((int)i, j + 1);
+            else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restrict__ q,
+                                                            const int *__restrict__ q_count,
+                                                            int *__restrict__ list, int *__restrict__ list_count)
+{
+    const i64 total = *q_count;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
+        list[atomicAdd(list_count, 1)] = q[t].x;
 }
 
 }  // namespace
 
-int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const i64 *conn,
-                          i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w,
-                          const double *pts, i64 *d_nfailed)
+// Launch the whole locate stage on ctx->stream (no synchronisation).  Scratch: two pass queues,
+// the slow list and their counters come from the context's scratch pool, so this must be the only
+// scratch user between mm_scratch_begin calls of the caller -- it calls mm_scratch_begin itself.
+int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const i64 *conn, i64 nelem,
+                          int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
+                          i64 *d_nfailed)
 {
     MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
     if (npoints == 0 || k == 0) return MM_OK;
+    MM_REQUIRE(npoints < (i64)0x7fffffff, "too many targets for one launch");
     const int block = 256;
-    const i64 grid = (npoints + block - 1) / block;
-    MM_REQUIRE(grid < (i64)0x7fffffff, "too many targets for one launch");
-    dim3 g((unsigned)grid), b(block);
-    if (conn_is_exodus)
-        hipLaunchKernelGGL((locate_hex8_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                           enc, nodes, w, pts, (unsigned long long *)d_nfailed);
-    else
-        hipLaunchKernelGGL((locate_hex8_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                           enc, nodes, w, pts, (unsigned long long *)d_nfailed);
+    const i64 full_grid = (npoints + block - 1) / block;
+    constexpr int kPasses = 8;
+
+    int rc = mm_scratch_begin(ctx, 2 * mm_round256((size_t)npoints * sizeof(int2)) +
+                                       mm_round256((size_t)npoints * sizeof(int)) + 4096);
+    if (rc != MM_OK) return rc;
+    int2 *qa = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    int2 *qb = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    int *slow = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
+    int *counters = (int *)mm_scratch_take(ctx, 256);  // [0..kPasses]: queue sizes, [15]: slow count
+    if (!qa || !qb || !slow || !counters) {
+        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+        return MM_ERR_ALLOC;
+    }
+    MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
+    int *slow_count = counters + 15;
+    for (int p = 0; p < kPasses; ++p) {
+        const int2 *q_in = p == 0 ? nullptr : ((p & 1) ? qa : qb);
+        int2 *q_out = (p & 1) ? qb : qa;
+        const int *q_in_count = p == 0 ? nullptr : counters + p;
+        int *q_out_count = counters + p + 1;
+        // pass 0 covers every target; later passes only know their size on the device, so they
+        // run a bounded grid with a grid-stride loop (the open set shrinks ~3x per pass)
+        i64 grid = p == 0 ? full_grid : (full_grid >> (p < 4 ? p : 4));
+        if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
+        dim3 g((unsigned)grid), b(block);
+        if (conn_is_exodus)
+            hipLaunchKernelGGL((locate_pass_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
+        else
+            hipLaunchKernelGGL((locate_pass_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
+    }
+    // whatever is still open after the last pass joins the slow list (reference-order kernel)
+    {
+        const int2 *q_last = (kPasses & 1) ? qa : qb;
+        const int *q_last_count = counters + kPasses;
+        i64 grid = full_grid >> 4;
+        if (grid < 64) grid = full_grid < 64 ? full_grid : 64;
+        hipLaunchKernelGGL(queue_to_list_kernel, dim3((unsigned)grid), dim3(block), 0, ctx->stream, q_last,
+                           q_last_count, slow, slow_count);
+        i64 sgrid = full_grid >> 3;
+        if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
+        dim3 g((unsigned)sgrid), b(block);
+        if (conn_is_exodus)
+            hipLaunchKernelGGL((locate_hex8_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count);
+        else
+            hipLaunchKernelGGL((locate_hex8_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count);
+    }
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }

@@ -5,7 +5,8 @@
 
 #include "mm_common.h"
 
-int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out);
+int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
+                      bool use_context_buffers);
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, i64 *idx_d,
                       double *dist_d);
 void mm_clear_status(void);
@@ -32,14 +33,12 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     mm_stage_reset(ctx);
     if (npoints == 0) return 0;
 
-    // Device buffers for this call.  The kNN build uses the context scratch itself, so the
-    // pipeline's own intermediates are separate allocations (freed at the end; the benchmark
-    // and the drivers reuse a context, so a caching layer can replace this later).
+    // Intermediates come from the context's grow-only buffer cache: after the first call with a
+    // given problem size there is no allocation, free or extra synchronisation in here.
     double *cen = nullptr;
     i64 *nn = nullptr;
     i64 *enc = (i64 *)enc_d;
     double *w = w_d;
-    bool own_enc = false, own_w = false;
     mm_knn_index *index = nullptr;
     int64_t result = MM_ERR_HIP;
     hipError_t e = hipSuccess;
@@ -52,17 +51,11 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
         goto done;                                                     \
     } while (0)
 
-    e = hipMalloc((void **)&cen, (size_t)nelem * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&nn, (size_t)npoints * (size_t)k * sizeof(i64));
-    if (e == hipSuccess && !enc) {
-        e = hipMalloc((void **)&enc, (size_t)npoints * 8 * sizeof(i64));
-        own_enc = true;
-    }
-    if (e == hipSuccess && !w) {
-        e = hipMalloc((void **)&w, (size_t)npoints * 8 * sizeof(double));
-        own_w = true;
-    }
-    if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_ALLOC, hipGetErrorString(e));
+    rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
+    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)k * sizeof(i64), (void **)&nn);
+    if (rc == MM_OK && !enc) rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * 8 * sizeof(i64), (void **)&enc);
+    if (rc == MM_OK && !w) rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * 8 * sizeof(double), (void **)&w);
+    if (rc != MM_OK) { result = rc; goto done; }
 
     // rows of failed points must read as zero (the reference's callers zero-initialise,
     // scripts/cli.py:77-78)
@@ -76,7 +69,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index);
+    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true);
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     if (rc != MM_OK) { result = rc; goto done; }
 
@@ -103,12 +96,8 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     result = ctx->h_counters[0];
 
 done:
-    (void)hipStreamSynchronize(ctx->stream);
-    if (index) mm_knn_destroy(nullptr, index);
-    if (cen) (void)hipFree(cen);
-    if (nn) (void)hipFree(nn);
-    if (own_enc && enc) (void)hipFree(enc);
-    if (own_w && w) (void)hipFree(w);
+    if (result < 0) (void)hipStreamSynchronize(ctx->stream);
+    if (index) mm_knn_destroy(nullptr, index);  // borrowed arrays stay in the context cache
     return result;
 #undef MM_PIPE_FAIL
 }
