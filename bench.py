@@ -33,14 +33,42 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured
 
 
 def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
-    """algorithmic bytes per launch of each stage (reference dtypes)."""
+    """algorithmic bytes per launch of each stage (reference dtypes).
+
+    knn_cell / locate_pass0 are single kernels inside the knn_query / locate stages and are
+    priced with the whole stage's algorithmic bytes (they do the stage's work; the other
+    kernels of the stage are its bookkeeping)."""
+    knn = n_targets * (24 + 8 * k) + n_elem * 24
+    loc = n_targets * (24 + 8 * k + 64 + 192 + 128)
     return {
         "centroid": n_elem * (8 * 8 + 8 * 24 + 24),
         "knn_build": n_elem * 24 * 2,                       # read centroids, write them cell-sorted
-        "knn_query": n_targets * (24 + 8 * k) + n_elem * 24,
-        "locate": n_targets * (24 + 8 * k + 64 + 192 + 128),
+        "knn_query": knn,
+        "locate": loc,
         "gather": n_targets * (128 + 72 * ncomp),
+        "knn_cell": knn,
+        "locate_pass0": loc,
     }
+
+
+#: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline)
+SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
+KERNEL_OF_STAGE = {"centroid": "centroid_kernel<3, 8>", "knn_cell": "knn_cell_kernel<20, 32>",
+                   "locate_pass0": "locate_pass_kernel<true> (first pass)", "gather": "gather8_kernel<true>"}
+
+
+def measured_traffic(kernel_stage):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    FETCH_SIZE doubled for wide streaming reads as MI355X_MICROARCH.md prescribes); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        return data.get(kernel_stage, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(pa, ca, pb, fields, k, sample_stride):
@@ -186,9 +214,11 @@ def main():
             gbps = abytes[s] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             stages[s] = {"ms": round(ms, 4), "algorithmic_bytes": abytes[s], "achieved_GBps": round(gbps, 1),
                          "frac": round(gbps / HBM_PEAK_GBPS, 4)}
-        dominant = max(STAGES, key=lambda s: stage_ms[s])
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": stages[dominant]["achieved_GBps"],
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": stages[dominant]["frac"], "traffic": None}
+        dominant = max(SINGLE_KERNEL_STAGES, key=lambda s: stage_ms[s])
+        roofline = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dominant], "stage": dominant,
+                    "achieved": stages[dominant]["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": stages[dominant]["frac"], "ms": stages[dominant]["ms"],
+                    "algorithmic_bytes": abytes[dominant], "traffic": measured_traffic(dominant)}
         line = {
             "metric": "interpolated points/sec, 10M->10M 3D mesh, 1 scalar field",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

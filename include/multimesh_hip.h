@@ -141,10 +141,12 @@ int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnod
 enum mm_stage {
     MM_STAGE_CENTROID = 0,
     MM_STAGE_KNN_BUILD = 1,
-    MM_STAGE_KNN_QUERY = 2,
-    MM_STAGE_LOCATE = 3,
+    MM_STAGE_KNN_QUERY = 2,    /* whole query: target sort + cell kernel + straggler kernel */
+    MM_STAGE_LOCATE = 3,       /* whole locate: all passes + reference-order kernel */
     MM_STAGE_GATHER = 4,
-    MM_STAGE_COUNT = 5
+    MM_STAGE_KNN_CELL = 5,     /* the kNN cell kernel alone (inside MM_STAGE_KNN_QUERY) */
+    MM_STAGE_LOCATE_PASS0 = 6, /* the first locate pass alone (inside MM_STAGE_LOCATE) */
+    MM_STAGE_COUNT = 7
 };
 int mm_set_profiling(mm_context *ctx, int on);
 int mm_last_timings(mm_context *ctx, double *ms, int n);

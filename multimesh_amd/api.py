@@ -1,0 +1,128 @@
+"""Drop-in for the interpolate-between-meshes entry points of reference ``multi_mesh/api.py`` and
+the hot-path command of ``multi_mesh/scripts/cli.py``.
+
+Same function names, argument meaning and return conventions as the reference; mesh arguments are
+:class:`multimesh_amd.mesh.HexMesh` array bundles because the reference's mesh readers (pyexodus,
+h5py, salvus) are not part of the hot path.  Every function here ends in
+HIP kernels through the C ABI of ``multi_mesh_hip.so``; there is no CPU fallback.
+
+Covered (hex8, the path the reference implements in its own C):
+  * :func:`interpolate_mesh_a_to_b`  -- reference scripts/cli.py:35-104
+  * :func:`interpolate_to_points`    -- reference api.py:320-350 / interpolator.py:931-977
+  * :func:`interpolate_to_mesh`      -- reference api.py:353-393
+The GLL (salvus.fem backed) entry points keep their names and raise NotImplementedError naming the
+SURVEY.md §8 row they wait for.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .device import default_context
+from .mesh import HexMesh
+
+TTI_PARAMS = ["VSH", "VSV", "VPV", "VPH", "RHO", "ETA", "QKAPPA", "QMU"]  # reference cli.py:58-59
+
+
+def _report(start):
+    # the reference prints wall-clock around every API call (api.py:39-57)
+    runtime = time.time() - start
+    if runtime >= 60:
+        print(f"Finished in time: {runtime / 60} minutes")
+    else:
+        print(f"Finished in time: {runtime} seconds")
+
+
+def latlondepth_to_xyz(latlondepth):
+    """reference utils.py:526-542 (r_earth = 6371000 m, geocentric latitude)."""
+    latlondepth = np.asarray(latlondepth, dtype=np.float64)
+    r = 6371000.0 - latlondepth[:, 2]
+    colat = np.deg2rad(90.0 - latlondepth[:, 0])
+    lon = np.deg2rad(latlondepth[:, 1])
+    return np.array([r * np.sin(colat) * np.cos(lon), r * np.sin(colat) * np.sin(lon), r * np.cos(colat)]).T
+
+
+def interpolate_operator(mesh_a: HexMesh, points, nelem_to_search=20, context=None):
+    """``(enclosing_elem_node_indices int64[N,8], weights f64[N,8], nfailed)`` for arbitrary points:
+    centroid -> kNN -> locate, i.e. reference cli.py:62-95 without the field loop.  This is the
+    persistable operator of the reference's ``stored_array`` split."""
+    ctx = context or default_context()
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    field = np.zeros((1, mesh_a.npoint))
+    _, enc, w, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, points, field,
+                                              nelem_to_search=nelem_to_search, want_operator=True)
+    return enc.numpy(), w.numpy(), nfailed
+
+
+def apply_operator(mesh_a: HexMesh, enclosing_elem_node_indices, weights, params, context=None):
+    """``np.sum(param_a[enc] * weights, axis=1)`` per parameter (reference cli.py:98-100) -> f64[N,C]."""
+    ctx = context or default_context()
+    return ctx.gather(mesh_a.fields_matrix(params), enclosing_elem_node_indices, weights).numpy()
+
+
+def interpolate_mesh_a_to_b(mesh_a: HexMesh, mesh_b: HexMesh, params=("TTI",), context=None):
+    """Interpolates values from mesh A onto the nodes of mesh B (reference cli.py:41-104).
+
+    Attaches every parameter to ``mesh_b`` and, like the reference, asserts that no point failed."""
+    params = list(params)
+    if params and params[0] == "TTI":
+        params = list(TTI_PARAMS)
+    ctx = context or default_context()
+    nelem_to_search = 20  # reference cli.py:69
+    values, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, mesh_b.points,
+                                           mesh_a.fields_matrix(params), nelem_to_search=nelem_to_search)
+    values = values.numpy()
+    for i, param in enumerate(params):
+        mesh_b.attach_field(param, values[:, i])
+    assert nfailed == 0, f"{nfailed} points could not be interpolated."
+    return mesh_b
+
+
+def interpolate_to_points(mesh, points, params_to_interp, make_spherical=False, geocentric=False,
+                          nelem_to_search=25, context=None):
+    """Maps values from a mesh to predefined points, xyz or geocentric latlondepth
+    (reference api.py:320-350).  Returns f64[npoints, nparams]; points that are not found get zero
+    (reference interpolator.py:963-977)."""
+    if make_spherical:
+        raise NotImplementedError("map_to_sphere (reference interpolator.py:1085-1144) is Earth-specific "
+                                  "pre-processing outside the hot path (SURVEY.md §2 #15)")
+    if geocentric:
+        points = latlondepth_to_xyz(points)
+    ctx = context or default_context()
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    vals, nfailed = ctx.interpolate_hex8(mesh.points, mesh.connectivity, points,
+                                         mesh.fields_matrix(params_to_interp), nelem_to_search=nelem_to_search)
+    if nfailed > 0:
+        print(nfailed, "points could not find an enclosing element. These points will be set to zero. "
+                       "Please check your domain or the interpolation tuning parameters")
+    return vals.numpy()
+
+
+def interpolate_to_mesh(old_mesh, new_mesh, params_to_interp=("VSV", "VSH", "VPV", "VPH"), context=None):
+    """Interpolate ``params_to_interp`` from old_mesh onto the nodes of new_mesh
+    (reference api.py:353-393, minus the Earth-specific sphere mapping).  Values that are not found
+    are given zero."""
+    start = time.time()
+    vals = interpolate_to_points(old_mesh, new_mesh.points, list(params_to_interp), context=context)
+    for i, param in enumerate(params_to_interp):
+        new_mesh.attach_field(param, vals[:, i])
+    _report(start)
+    return new_mesh
+
+
+def _gll(name, row):
+    def f(*args, **kwargs):
+        raise NotImplementedError(f"{name}: the GLL (salvus.fem backed) path is SURVEY.md §8 row {row}; "
+                                  "only the hex8 path of the reference's own C library is implemented so far")
+    f.__name__ = name
+    return f
+
+
+exodus_2_gll = _gll("exodus_2_gll", "A10 / §8f-2")
+gll_2_gll = _gll("gll_2_gll", "A10")
+gll_2_gll_layered = _gll("gll_2_gll_layered", "A10 / §8f-4")
+gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "A10 / §8f-4")
+gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "A10 / §8f-4")
+gll_2_exodus = _gll("gll_2_exodus", "A10 / §8f-2")
+query_model = _gll("query_model", "A10")

@@ -822,9 +822,11 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
 {
     constexpr int CAP = K + 12;
     static const int dbg_stop = getenv("MM_KNN_DBG_STOP") ? atoi(getenv("MM_KNN_DBG_STOP")) : 0;
+    mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3(ix->dims[2], ix->dims[1], ix->dims[0]), dim3(kWave), 0, ctx->stream, g,
                        ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, ix->ndim, kout, tstart, perm,
                        tsorted, idx, dist, fb_list, fb_count, dbg_stop);
+    mm_stage_end(ctx, MM_STAGE_KNN_CELL);
     launch_generic<K>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
 

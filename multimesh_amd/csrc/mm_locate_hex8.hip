@@ -400,12 +400,14 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, co
         i64 grid = p == 0 ? full_grid : (full_grid >> (p < 4 ? p : 4));
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)grid), b(block);
+        if (p == 0) mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
         if (conn_is_exodus)
             hipLaunchKernelGGL((locate_pass_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
                                nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
         else
             hipLaunchKernelGGL((locate_pass_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
                                nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
+        if (p == 0) mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     }
     // whatever is still open after the last pass joins the slow list (reference-order kernel)
     {

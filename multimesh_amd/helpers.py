@@ -28,7 +28,7 @@ cache = []
 
 MM_OK = 0
 MM_KNN_MAX_K = 64
-STAGES = ("centroid", "knn_build", "knn_query", "locate", "gather")
+STAGES = ("centroid", "knn_build", "knn_query", "locate", "gather", "knn_cell", "locate_pass0")
 
 #: every symbol include/multimesh_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
