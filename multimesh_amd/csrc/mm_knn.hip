@@ -450,7 +450,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
                                                             int dbg_stop)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
-    __shared__ float4 tile[kTileCap];
+    __shared__ float4 tile[kTileCap + 1];                       // +1: far-away sentinel entry
+    __shared__ unsigned s_pk[kSlots / 4][kWave];                // bucket numbers of each lane's slots
     __shared__ double s_bd[CAP][kMaxGroups];
     __shared__ int s_bx[CAP][kMaxGroups];                       // source position, then source id
     __shared__ unsigned s_hist[kHistBuckets + 1][kMaxGroups];   // last row: sink for idle lanes
@@ -459,9 +460,22 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
     __shared__ unsigned long long s_seen[kMaxGroups];
 
     const int lane = threadIdx.x;
-    // grid = (nz, ny, nx): the cell's coordinates come straight from the block index
-    const int cz = blockIdx.x, cy = blockIdx.y, cx = blockIdx.z;
-    const int cell = (cx * g.ny + cy) * g.nz + cz;
+    // XCD-aware cell -> workgroup map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b
+    // and b+8 share one), and each XCD has a private 4 MiB L2.  A cell's 27-cell neighbourhood
+    // overlaps its neighbours', so every source is staged ~27 times: with the natural order those
+    // re-reads land on different XCDs and only the Infinity Cache catches them (measured: ~8x the
+    // algorithmic bytes crossed the fabric).  Here XCD x owns a contiguous slab of (cx,cy) columns,
+    // walked z-fastest, so a source's re-reads come from the same L2.  Speed only: any placement
+    // gives the same result.
+    const int ncols = g.nx * g.ny;
+    const int cols_per_xcd = (ncols + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const int m = blockIdx.x >> 3;
+    const int col = xcd * cols_per_xcd + m / g.nz;
+    if (m / g.nz >= cols_per_xcd || col >= ncols) return;
+    const int cz = m % g.nz;
+    const int cx = col / g.ny, cy = col % g.ny;
+    const int cell = col * g.nz + cz;
 
     // metadata: the cell's target range and the 9 column runs of its neighbourhood, all loads
     // issued together (every address depends on the block index only)
@@ -567,12 +581,13 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
             }
         }
     }
+    if (lane == 0) tile[total] = make_float4(1e30f, 1e30f, 1e30f, 0.f);  // slots past the end read this
     if (dbg_stop == 1) return;  // diagnostic builds only (MM_KNN_DBG_STOP): time the phases
 
     for (int r0 = 0; r0 < tn; r0 += tpw) {
         const int tt = r0 + tg;
         const bool valid = tt < tn;
-        const i64 i = valid && dbg_stop != 23 ? (i64)perm[t0 + tt] : 0;  // only needed for the output row
+        const i64 i = valid ? (i64)perm[t0 + tt] : 0;  // only needed for the output row
         const double px = valid ? npx : ox;
         const double py = valid ? npy : oy;
         const double pz = valid ? npz : oz;
@@ -587,37 +602,35 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
         const float tx = (float)(px - ox), ty = (float)(py - oy), tz = (float)(pz - oz);
         const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy + g.hz));
 
-        if (dbg_stop != 22) for (int q = lane; q < (kHistBuckets + 1) * kMaxGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
+        for (int q = lane; q < (kHistBuckets + 1) * kMaxGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
         if (lane < kMaxGroups) {
             s_jb[lane] = kHistBuckets;
             s_seen[lane] = 0ull;
         }
         wave_sync();  // tile staged (first round), counters cleared
 
-        // ---- P1: histogram of fp32 squared distances; bucket numbers packed 4 per register
-        unsigned pk[kSlots / U];
+        // ---- P1: histogram of fp32 squared distances; the bucket numbers of a lane's slots are
+        // kept (4 per word) in LDS for P2.  Slots past the end of the tile read the far-away
+        // sentinel, and an idle group's target is moved far away, so the loop has no liveness tests:
+        // such pairs fall into the last bucket, which is never counted nor collected.
+        const float qx = valid ? tx : 1e30f;
+        for (int m = 0; m < nbatch; ++m) {
+            float4 q4[U];
 #pragma unroll
-        for (int m = 0; m < kSlots / U; ++m) {
-            pk[m] = 0xffffffffu;
-            if (m < nbatch) {
-                float4 q4[U];
+            for (int u = 0; u < U; ++u) q4[u] = tile[min(sl + (m * U + u) * S, total)];
+            unsigned packed = 0u;
 #pragma unroll
-                for (int u = 0; u < U; ++u) q4[u] = dbg_stop == 21 ? make_float4(tx + u, ty + m, tz, 0.f) : tile[min(sl + (m * U + u) * S, total - 1)];
-                unsigned packed = 0u;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float fx = q4[u].x - tx, fy = q4[u].y - ty, fz = q4[u].z - tz;
-                    const float a = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-                    const bool live = valid && sl + (m * U + u) * S < total;
-                    // NaN -> last bucket (fminf returns the non-NaN operand).  The last bucket means
-                    // "beyond the histogram range": most candidates land there, and counting them
-                    // would serialise the LDS atomic on one address, so they are not counted.
-                    const int b = (int)fminf(a * scale, (float)(kHistBuckets - 1));
-                    if (live && b < kHistBuckets - 1 && dbg_stop != 20) atomicAdd(&s_hist[b][tg], 1u);
-                    packed |= (live ? (unsigned)b : 0xffu) << (8 * u);
-                }
-                pk[m] = packed;
+            for (int u = 0; u < U; ++u) {
+                const float fx = q4[u].x - qx, fy = q4[u].y - ty, fz = q4[u].z - tz;
+                const float a = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                // NaN -> last bucket (fminf returns the non-NaN operand).  The last bucket means
+                // "beyond the histogram range": most candidates land there, and counting them
+                // would serialise the LDS atomic on one address, so they are not counted.
+                const int b = (int)fminf(a * scale, (float)(kHistBuckets - 1));
+                if (b < kHistBuckets - 1) atomicAdd(&s_hist[b][tg], 1u);
+                packed |= (unsigned)b << (8 * u);
             }
+            s_pk[m][lane] = packed;
         }
         wave_sync();
         if (dbg_stop == 2 || (dbg_stop >= 20 && dbg_stop <= 23)) return;
@@ -655,11 +668,11 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
         // ---- P2: candidates in buckets <= jb+1 go to the target's list.  Each lane marks its
         // qualifying slots in a bit mask; a group prefix sum of the counts gives the list offsets.
         unsigned qmask = 0u;
-#pragma unroll
-        for (int m = 0; m < kSlots / U; ++m) {
+        for (int m = 0; m < nbatch; ++m) {
+            const unsigned packed = s_pk[m][lane];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = (int)((pk[m] >> (8 * u)) & 0xffu);
+                const int b = (int)((packed >> (8 * u)) & 0xffu);
                 qmask |= (b <= jb + 1 ? 1u : 0u) << (m * U + u);
             }
         }
@@ -765,9 +778,18 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
             // the group's lanes write the target's row side by side (coalesced 8-byte stores)
             i64 *row = idx_out + i * kout;
             double *drow = dist_out ? dist_out + i * kout : nullptr;
-            for (int e = sl; e < kout; e += S) {
-                row[e] = (i64)s_bx[e][tg];
-                if (drow) drow[e] = sqrt(s_bd[e][tg]);
+            if ((kout & 1) == 0) {
+                // 16-byte stores (rows are 16-byte aligned when k is even): fewer, fuller writes
+                for (int e = 2 * sl; e < kout; e += 2 * S) {
+                    *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_bx[e][tg], (i64)s_bx[e + 1][tg]);
+                    if (drow)
+                        *reinterpret_cast<double2 *>(drow + e) = make_double2(sqrt(s_bd[e][tg]), sqrt(s_bd[e + 1][tg]));
+                }
+            } else {
+                for (int e = sl; e < kout; e += S) {
+                    row[e] = (i64)s_bx[e][tg];
+                    if (drow) drow[e] = sqrt(s_bd[e][tg]);
+                }
             }
         }
         if (dbg_stop == 11) return;
@@ -822,8 +844,11 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
 {
     constexpr int CAP = K + 12;
     static const int dbg_stop = getenv("MM_KNN_DBG_STOP") ? atoi(getenv("MM_KNN_DBG_STOP")) : 0;
+    // 8 XCD slabs of ceil(columns/8) cell columns each (see the kernel's workgroup map)
+    const i64 cols = (i64)ix->dims[0] * ix->dims[1];
+    const i64 cell_grid = 8 * ((cols + 7) / 8) * ix->dims[2];
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
-    hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3(ix->dims[2], ix->dims[1], ix->dims[0]), dim3(kWave), 0, ctx->stream, g,
+    hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
                        ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, ix->ndim, kout, tstart, perm,
                        tsorted, idx, dist, fb_list, fb_count, dbg_stop);
     mm_stage_end(ctx, MM_STAGE_KNN_CELL);
