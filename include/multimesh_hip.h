@@ -125,6 +125,25 @@ int mm_gather(mm_context *ctx, const double *fields_d, int64_t nsrc, int64_t nco
               const int64_t *ids_d, const double *w_d, int64_t npoints, int64_t P, double *out_d,
               int out_point_major);
 
+/* A10 -- GLL elements (order 1, 2, 4; dim 2, 3): element search + Lagrange coefficients; replaces
+ * the per-point loop get_element_weights.check_inside at reference
+ * components/interpolator.py:1181-1233 (tolerance and snap_to_nearest as there; 1.03 / 0 gives the
+ * layered variant :1271-1297).  The inverse transform and the coefficients come from salvus.fem in
+ * the reference (absent): PARITY UNPINNED, numerics defined in mm_locate_gll.hip / the oracle.
+ * gll_points_d f64[nelem][P][dim] with P = (order+1)^dim, control node p = i + (order+1) j + ...;
+ * nn_d int64[npoints][k]; elem_d int64[npoints] (-1 = not found); coeffs_d f64[npoints][P].
+ * Returns the number of points without an element, or a negative MM_ERR_*. */
+int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t nelem_to_search, int64_t npoints,
+                      const int64_t *nearest_element_indices_d, const double *gll_points_d, int64_t nelem,
+                      const double *points_d, double tolerance, int snap_to_nearest, int64_t *elem_d,
+                      double *coeffs_d);
+
+/* Element-nodal gather np.sum(coeffs * field[elem_indices], axis=1) (reference interpolator.py:976):
+ * fields_d f64[ncomp][nelem][P]; points with elem -1 give 0.  NumPy's summation order. */
+int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64_t ncomp,
+                   const int64_t *elem_d, const double *coeffs_d, int64_t npoints, int64_t P, double *out_d,
+                   int out_point_major);
+
 /* The whole hot path of reference scripts/cli.py:62-100 on resident arrays:
  * centroid -> search grid -> kNN -> locate -> gather.  connectivity_d is the mesh's own
  * (exodus-order) hex8 connectivity.  enc_d / w_d (nullable) receive the interpolation

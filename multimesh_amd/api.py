@@ -111,6 +111,55 @@ def interpolate_to_mesh(old_mesh, new_mesh, params_to_interp=("VSV", "VSH", "VPV
     return new_mesh
 
 
+class GllMesh:
+    """Element-nodal GLL mesh bundle: what the reference reads from a Salvus mesh for the GLL path
+    (``mesh.points[mesh.connectivity]``, ``mesh.shape_order``, ``mesh.element_nodal_fields``;
+    interpolator.py:954-976)."""
+
+    def __init__(self, gll_points, shape_order, element_nodal_fields=None):
+        self.gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)   # [E, P, dim]
+        self.shape_order = int(shape_order)
+        self.element_nodal_fields = {k: np.ascontiguousarray(v, dtype=np.float64)
+                                     for k, v in (element_nodal_fields or {}).items()}
+
+    @property
+    def nelem(self):
+        return self.gll_points.shape[0]
+
+    def get_element_centroid(self):
+        # the reference takes the mean of the control nodes (salvus_mesh_reader.py:99-100)
+        return self.gll_points.mean(axis=1)
+
+
+def get_element_weights(gll_points, shape_order, centroid_tree, points, nelem_to_search=25, tolerance=1.05,
+                        snap_to_nearest=False, context=None):
+    """Enclosing element and interpolation coefficients of every point
+    (reference interpolator.py:1147-1255).  ``centroid_tree``: a :class:`multimesh_amd.device.KnnIndex`
+    over the element centroids, or the centroid array itself.  Returns ``(elems int64[N] with -1 for
+    "not found", coeffs f64[N, P])``."""
+    ctx = context or default_context()
+    tree = centroid_tree if hasattr(centroid_tree, "query") else ctx.knn_build(centroid_tree)
+    nn = tree.query(points, nelem_to_search)
+    elem, coeffs, _ = ctx.locate_gll(shape_order, nn, gll_points, points, tolerance, snap_to_nearest)
+    return elem.numpy(), coeffs.numpy()
+
+
+def interpolate_gll_to_points(mesh: GllMesh, points, params_to_interp, nelem_to_search=25, tolerance=1.05,
+                              context=None):
+    """The GLL form of ``interpolate_to_points`` (reference interpolator.py:931-977): centroid tree,
+    element weights, then ``np.sum(coeffs * field[elem], axis=1)`` per parameter -> f64[N, C]."""
+    ctx = context or default_context()
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    tree = ctx.knn_build(mesh.get_element_centroid())
+    nn = tree.query(points, nelem_to_search)
+    elem, coeffs, num_failed = ctx.locate_gll(mesh.shape_order, nn, mesh.gll_points, points, tolerance, False)
+    if num_failed > 0:
+        print(num_failed, "points could not find an enclosing element. These points will be set to zero. "
+                          "Please check your domain or the interpolation tuning parameters")
+    fields = np.stack([mesh.element_nodal_fields[p] for p in params_to_interp])
+    return ctx.gather_elem(fields, elem, coeffs).numpy()
+
+
 def _gll(name, row):
     def f(*args, **kwargs):
         raise NotImplementedError(f"{name}: the GLL (salvus.fem backed) path is SURVEY.md §8 row {row}; "

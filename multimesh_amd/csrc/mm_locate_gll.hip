@@ -1,0 +1,399 @@
+// A10 -- GLL elements (order 1, 2, 4; 2-D and 3-D): element search by Newton inversion of the
+// isoparametric map, tensor-product Lagrange interpolation coefficients, element-nodal gather.
+// Replaces the per-point Python loops of reference multi_mesh/components/interpolator.py:
+//   get_element_weights.check_inside :1181-1233 (control flow reproduced here),
+//   inverse_transform :1370-1386 and get_coefficients :1337-1347 (thin wrappers over the
+//   proprietary salvus.fem package, which is absent: PARITY UNPINNED -- the numerics below are
+//   this project's own definition, identical to oracle/mm_oracle.c "A10", pinned by analytic
+//   properties: partition of unity, Kronecker property at the nodes, exact reproduction of
+//   polynomials up to the element order, order-1 == the hex8 path),
+//   and the gather np.sum(coeffs * field[elem_indices], axis=1) :976.
+//
+// Numerics: tensor-product Lagrange basis on the GLL nodes (order 1: -1,1; order 2: -1,0,1;
+// order 4: -1,-sqrt(3/7),0,sqrt(3/7),1), node index p = i + (n+1) j + (n+1)^2 k; Newton from
+// xi = 0 with the analytic Jacobian and a cofactor solve; converged when the largest update
+// component is < 1e-12, at most 25 updates; NaN when an iterate leaves [-10,10] or the iteration
+// does not converge.  Same operation order as the oracle, no fused multiply-add.
+//
+// One lane per target, control nodes streamed from L2 each Newton step (first version: correct
+// and complete; the element-centric LDS-tiled variant is future work).
+#include <math.h>
+
+#include "mm_common.h"
+
+namespace {
+
+template <int ORDER>
+__device__ __forceinline__ void gll_nodes(double (&g)[ORDER + 1])
+{
+    if (ORDER == 1) {
+        g[0] = -1.0;
+        g[ORDER] = 1.0;
+    } else if (ORDER == 2) {
+        g[0] = -1.0;
+        g[1] = 0.0;
+        g[ORDER] = 1.0;
+    } else {
+        const double a = sqrt(3.0 / 7.0);
+        g[0] = -1.0;
+        g[1] = -a;
+        g[ORDER / 2] = 0.0;
+        g[ORDER - 1] = a;
+        g[ORDER] = 1.0;
+    }
+}
+
+// 1-D Lagrange values and derivatives, product formulas in a fixed loop order (== oracle)
+template <int ORDER>
+__device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double x, double (&l)[ORDER + 1],
+                                            double (&dl)[ORDER + 1])
+{
+    constexpr int n = ORDER + 1;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double v = 1.0;
+#pragma unroll
+        for (int m = 0; m < n; ++m)
+            if (m != i) v = v * ((x - g[m]) / (g[i] - g[m]));
+        l[i] = v;
+        double d = 0.0;
+#pragma unroll
+        for (int m = 0; m < n; ++m) {
+            if (m == i) continue;
+            double t = 1.0 / (g[i] - g[m]);
+#pragma unroll
+            for (int q = 0; q < n; ++q)
+                if (q != i && q != m) t = t * ((x - g[q]) / (g[i] - g[q]));
+            d = d + t;
+        }
+        dl[i] = d;
+    }
+}
+
+template <int ORDER, int DIM>
+struct Gll {
+    static constexpr int n = ORDER + 1;
+    static constexpr int P = DIM == 3 ? n * n * n : n * n;
+
+    // reference coordinates of pnt inside the element whose control nodes start at ctrl
+    // ([P][DIM]); NaNs when the iteration fails
+    static __device__ __forceinline__ void inverse_transform(const double (&pnt)[DIM],
+                                                             const double *__restrict__ ctrl, double (&xi)[DIM])
+    {
+        double g[n];
+        gll_nodes<ORDER>(g);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) xi[d] = 0.0;
+        for (int it = 0; it < 25; ++it) {
+            double l[DIM][n], dl[DIM][n];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) lagrange_1d<ORDER>(g, xi[d], l[d], dl[d]);
+            double x[DIM], J[DIM][DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                x[a] = 0.0;
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) J[a][b] = 0.0;
+            }
+            if (DIM == 3) {
+#pragma unroll
+                for (int k = 0; k < n; ++k)
+#pragma unroll
+                    for (int j = 0; j < n; ++j)
+#pragma unroll
+                        for (int i = 0; i < n; ++i) {
+                            const double *X = ctrl + 3 * (i + n * (j + n * k));
+                            const double w = (l[0][i] * l[1][j]) * l[DIM - 1][k];
+                            const double g0 = (dl[0][i] * l[1][j]) * l[DIM - 1][k];
+                            const double g1 = (l[0][i] * dl[1][j]) * l[DIM - 1][k];
+                            const double g2 = (l[0][i] * l[1][j]) * dl[DIM - 1][k];
+#pragma unroll
+                            for (int a = 0; a < DIM; ++a) {
+                                const double Xa = X[a];
+                                x[a] = x[a] + w * Xa;
+                                J[a][0] = J[a][0] + g0 * Xa;
+                                J[a][1] = J[a][1] + g1 * Xa;
+                                J[a][DIM - 1] = J[a][DIM - 1] + g2 * Xa;
+                            }
+                        }
+            } else {
+#pragma unroll
+                for (int j = 0; j < n; ++j)
+#pragma unroll
+                    for (int i = 0; i < n; ++i) {
+                        const double *X = ctrl + 2 * (i + n * j);
+                        const double w = l[0][i] * l[1][j];
+                        const double g0 = dl[0][i] * l[1][j];
+                        const double g1 = l[0][i] * dl[1][j];
+#pragma unroll
+                        for (int a = 0; a < DIM; ++a) {
+                            const double Xa = X[a];
+                            x[a] = x[a] + w * Xa;
+                            J[a][0] = J[a][0] + g0 * Xa;
+                            J[a][1] = J[a][1] + g1 * Xa;
+                        }
+                    }
+            }
+            double r[DIM], dxi[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) r[a] = x[a] - pnt[a];
+            if (DIM == 3) {
+                const double c00 = J[1][1] * J[DIM - 1][DIM - 1] - J[1][DIM - 1] * J[DIM - 1][1];
+                const double c01 = J[1][DIM - 1] * J[DIM - 1][0] - J[1][0] * J[DIM - 1][DIM - 1];
+                const double c02 = J[1][0] * J[DIM - 1][1] - J[1][1] * J[DIM - 1][0];
+                const double det = (J[0][0] * c00 + J[0][1] * c01) + J[0][DIM - 1] * c02;
+                const double rdet = 1.0 / det;
+                const double i00 = c00 * rdet;
+                const double i01 = (J[0][DIM - 1] * J[DIM - 1][1] - J[0][1] * J[DIM - 1][DIM - 1]) * rdet;
+                const double i02 = (J[0][1] * J[1][DIM - 1] - J[0][DIM - 1] * J[1][1]) * rdet;
+                const double i10 = c01 * rdet;
+                const double i11 = (J[0][0] * J[DIM - 1][DIM - 1] - J[0][DIM - 1] * J[DIM - 1][0]) * rdet;
+                const double i12 = (J[0][DIM - 1] * J[1][0] - J[0][0] * J[1][DIM - 1]) * rdet;
+                const double i20 = c02 * rdet;
+                const double i21 = (J[0][1] * J[DIM - 1][0] - J[0][0] * J[DIM - 1][1]) * rdet;
+                const double i22 = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rdet;
+                dxi[0] = (i00 * r[0] + i01 * r[1]) + i02 * r[DIM - 1];
+                dxi[1] = (i10 * r[0] + i11 * r[1]) + i12 * r[DIM - 1];
+                dxi[DIM - 1] = (i20 * r[0] + i21 * r[1]) + i22 * r[DIM - 1];
+            } else {
+                const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+                const double rdet = 1.0 / det;
+                dxi[0] = (J[1][1] * r[0] - J[0][1] * r[1]) * rdet;
+                dxi[1] = (J[0][0] * r[1] - J[1][0] * r[0]) * rdet;
+            }
+            double step = 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                xi[a] = xi[a] - dxi[a];
+                if (fabs(dxi[a]) > step) step = fabs(dxi[a]);
+                if (!(fabs(xi[a]) <= 10.0)) bad = true;  // also catches NaN
+            }
+            if (bad) break;
+            if (step < 1e-12) return;
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) xi[d] = NAN;
+    }
+
+    static __device__ __forceinline__ void coefficients(const double (&xi)[DIM], double *__restrict__ out)
+    {
+        double g[n];
+        gll_nodes<ORDER>(g);
+        double l[DIM][n], dl[DIM][n];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) lagrange_1d<ORDER>(g, xi[d], l[d], dl[d]);
+        if (DIM == 3) {
+#pragma unroll
+            for (int k = 0; k < n; ++k)
+#pragma unroll
+                for (int j = 0; j < n; ++j)
+#pragma unroll
+                    for (int i = 0; i < n; ++i) out[i + n * (j + n * k)] = (l[0][i] * l[1][j]) * l[DIM - 1][k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < n; ++j)
+#pragma unroll
+                for (int i = 0; i < n; ++i) out[i + n * j] = l[0][i] * l[1][j];
+        }
+    }
+};
+
+// control flow of reference interpolator.py:1181-1233 (see the oracle's mmo_locate_gll)
+template <int ORDER, int DIM>
+__global__ __launch_bounds__(64) void locate_gll_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+                                                        const double *__restrict__ gll_points, i64 nelem,
+                                                        const double *__restrict__ points, double tolerance,
+                                                        int snap_to_nearest, i64 *__restrict__ elem,
+                                                        double *__restrict__ coeffs,
+                                                        unsigned long long *__restrict__ nmissing)
+{
+    using G = Gll<ORDER, DIM>;
+    constexpr int P = G::P;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool missing = false;
+    if (i < npoints) {
+        double pnt[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
+        double best_xi[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) best_xi[d] = 10e9;
+        double best_val = 10e9;
+        i64 best_elem = 0;
+        bool found = false;
+        double xi[DIM];
+        for (i64 j = 0; j < k && !found; ++j) {
+            const i64 e = nn[i * k + j];
+            if (e < 0 || e >= nelem) continue;
+            G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
+            bool isnan_any = false;
+            double worst = 0.0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                if (xi[d] != xi[d]) isnan_any = true;
+                if (fabs(xi[d]) > worst) worst = fabs(xi[d]);
+            }
+            if (isnan_any) continue;
+            if (worst < best_val) {
+                best_val = worst;
+                best_elem = e;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) best_xi[d] = xi[d];
+            }
+            bool inside = true;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d)
+                if (!(fabs(xi[d]) < tolerance)) inside = false;
+            if (inside) {
+                elem[i] = e;
+                G::coefficients(xi, coeffs + i * P);
+                found = true;
+            }
+        }
+        if (!found) {
+            if (snap_to_nearest) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    double v = best_xi[d];
+                    if (v < -1.02) v = -1.02;
+                    if (v > 1.02) v = 1.02;
+                    best_xi[d] = v;
+                }
+                elem[i] = best_elem;
+                G::coefficients(best_xi, coeffs + i * P);
+            } else {
+                elem[i] = -1;
+                for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                missing = true;
+            }
+        }
+    }
+    const unsigned long long mask = __ballot(missing);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nmissing, (unsigned long long)__popcll(mask));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v);
+    int hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Element-nodal gather with NumPy's row-sum order (see mm_gather.hip): 8 lanes per target, lane j
+// owns the running partial r[j]; the node "ids" are implicit: elem * P + p.
+template <bool POINT_MAJOR>
+__global__ __launch_bounds__(256) void gather_elem_kernel(const double *__restrict__ fields, i64 nelem, int ncomp,
+                                                          const i64 *__restrict__ elem,
+                                                          const double *__restrict__ coeffs, i64 npoints, int P,
+                                                          double *__restrict__ out)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n_raw = t >> 3;
+    const int j = (int)(t & 7);
+    const int group_base = (threadIdx.x & 63) & ~7;
+    const bool valid = n_raw < npoints;
+    const i64 n = valid ? n_raw : npoints - 1;
+    const i64 e_raw = elem[n];
+    const i64 e = (unsigned long long)e_raw < (unsigned long long)nelem ? e_raw : 0;  // -1 (not found): zeros
+    const double *crow = coeffs + n * P;
+    const int tail = P & 7;
+    const int nfull = P - tail;
+    for (int c = 0; c < ncomp; ++c) {
+        const double *f = fields + ((i64)c * nelem + e) * P;
+        double res;
+        if (P < 8) {
+            const double a = j < P ? crow[j] * f[j] : 0.0;
+            res = 0.;
+            for (int i = 0; i < P; ++i) res += __shfl(a, group_base + i);
+        } else {
+            double r = crow[j] * f[j];
+            for (int i = 8; i < nfull; i += 8) r += crow[i + j] * f[i + j];
+            double s = r + dpp_f64<0xB1>(r);
+            s = s + dpp_f64<0x4E>(s);
+            s = s + dpp_f64<0x141>(s);
+            const double a = j < tail ? crow[nfull + j] * f[nfull + j] : 0.0;
+            res = s;
+            for (int i = 0; i < tail; ++i) res += __shfl(a, group_base + i);
+        }
+        if (valid && j == 0) {
+            if (POINT_MAJOR) out[n * ncomp + c] = res;
+            else out[(i64)c * npoints + n] = res;
+        }
+    }
+}
+
+template <int ORDER, int DIM>
+void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const double *gll, i64 nelem,
+                   const double *pts, double tol, int snap, i64 *elem, double *coeffs, unsigned long long *nmiss)
+{
+    const i64 grid = (npoints + 63) / 64;
+    hipLaunchKernelGGL((locate_gll_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k, npoints, nn,
+                       gll, nelem, pts, tol, snap, elem, coeffs, nmiss);
+}
+
+}  // namespace
+
+extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k, int64_t npoints,
+                                 const int64_t *nn_d, const double *gll_points_d, int64_t nelem,
+                                 const double *points_d, double tolerance, int snap_to_nearest, int64_t *elem_d,
+                                 double *coeffs_d)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(order == 1 || order == 2 || order == 4, "order must be 1, 2 or 4");
+    MM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    MM_REQUIRE(k >= 0 && npoints >= 0 && nelem >= 0, "negative size");
+    MM_REQUIRE(npoints == 0 || (elem_d && coeffs_d && points_d), "null array");
+    MM_REQUIRE(npoints == 0 || k == 0 || (nn_d && gll_points_d), "null array");
+    MM_REQUIRE(npoints < (int64_t)0x7fffffff * 64, "too many targets for one launch");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(i64), ctx->stream));
+    if (npoints > 0) {
+        mm_stage_begin(ctx, MM_STAGE_LOCATE);
+        unsigned long long *nm = (unsigned long long *)ctx->d_counters;
+        const i64 *nn = (const i64 *)nn_d;
+        i64 *el = (i64 *)elem_d;
+#define MM_GLL_CASE(O, D)                                                                                      \
+    if (order == O && dim == D)                                                                                \
+        launch_locate<O, D>(ctx, k, npoints, nn, gll_points_d, nelem, points_d, tolerance, snap_to_nearest, el, \
+                            coeffs_d, nm);
+        MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
+#undef MM_GLL_CASE
+        mm_stage_end(ctx, MM_STAGE_LOCATE);
+        MM_HIP_CHECK(hipGetLastError());
+    }
+    MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ctx->h_counters[0];
+}
+
+extern "C" int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64_t ncomp,
+                              const int64_t *elem_d, const double *coeffs_d, int64_t npoints, int64_t P,
+                              double *out_d, int out_point_major)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(nelem >= 0 && ncomp >= 0 && npoints >= 0, "negative size");
+    MM_REQUIRE(P >= 1 && P <= 128, "P must be in 1..128");
+    MM_REQUIRE(ncomp < (1 << 20), "ncomp too large");
+    MM_REQUIRE(npoints == 0 || ncomp == 0 || (fields_d && elem_d && coeffs_d && out_d), "null array");
+    MM_REQUIRE(npoints == 0 || ncomp == 0 || nelem >= 1, "empty source mesh");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    if (npoints == 0 || ncomp == 0) return MM_OK;
+    const i64 grid = (npoints * 8 + 255) / 256;
+    MM_REQUIRE(grid < (i64)0x7fffffff, "too many targets for one launch");
+    mm_stage_begin(ctx, MM_STAGE_GATHER);
+    if (out_point_major)
+        hipLaunchKernelGGL((gather_elem_kernel<true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, fields_d, nelem,
+                           (int)ncomp, (const i64 *)elem_d, coeffs_d, npoints, (int)P, out_d);
+    else
+        hipLaunchKernelGGL((gather_elem_kernel<false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, fields_d,
+                           nelem, (int)ncomp, (const i64 *)elem_d, coeffs_d, npoints, (int)P, out_d);
+    mm_stage_end(ctx, MM_STAGE_GATHER);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}

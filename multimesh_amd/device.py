@@ -220,6 +220,43 @@ class Context:
                                  1 if point_major else 0), "mm_gather")
         return out
 
+    # ---- A10 (GLL) ------------------------------------------------------------------------
+    def locate_gll(self, shape_order, nearest_element_indices, gll_points, points, tolerance=1.05,
+                   snap_to_nearest=False):
+        """``get_element_weights`` core (reference interpolator.py:1181-1233) for
+        gll_points f64[E, (order+1)^dim, dim].  Returns (elem int64[N], coeffs f64[N,P], nmissing)."""
+        nn = self.asdevice(nearest_element_indices, np.int64)
+        gp = self.asdevice(gll_points, np.float64)
+        pts = self.asdevice(points, np.float64)
+        nelem, P, dim = gp.shape
+        if P != (shape_order + 1) ** dim or pts.shape[1] != dim:
+            raise ValueError("gll_points must be [nelem, (order+1)^dim, dim] and points [N, dim]")
+        n = pts.shape[0]
+        k = nn.shape[1] if len(nn.shape) == 2 else 0
+        elem = self.empty((n,), np.int64)
+        coeffs = self.empty((n, P), np.float64)
+        miss = check(self.lib.mm_locate_gll(self.handle, shape_order, dim, k, n, nn.ptr, gp.ptr, nelem, pts.ptr,
+                                            float(tolerance), 1 if snap_to_nearest else 0, elem.ptr, coeffs.ptr),
+                     "mm_locate_gll")
+        return elem, coeffs, int(miss)
+
+    def gather_elem(self, element_nodal_fields, elem, coeffs, point_major=True):
+        """``np.sum(coeffs * field[elem], axis=1)`` (reference interpolator.py:976);
+        element_nodal_fields f64[C, E, P] (or [E, P]) -> f64[N, C]."""
+        f = self.asdevice(element_nodal_fields, np.float64)
+        if len(f.shape) == 2:
+            f = DeviceArray(self, f.ptr, (1,) + f.shape, f.dtype, owner=False, keepalive=f)
+        el = self.asdevice(elem, np.int64)
+        co = self.asdevice(coeffs, np.float64)
+        ncomp, nelem, P = f.shape
+        n = el.shape[0]
+        if co.shape != (n, P):
+            raise ValueError("coeffs must be [N, P]")
+        out = self.empty((n, ncomp) if point_major else (ncomp, n), np.float64)
+        check(self.lib.mm_gather_elem(self.handle, f.ptr, nelem, ncomp, el.ptr, co.ptr, n, P, out.ptr,
+                                      1 if point_major else 0), "mm_gather_elem")
+        return out
+
     # ---- fused ---------------------------------------------------------------------------
     def interpolate_hex8(self, nodes, connectivity, points, fields, nelem_to_search=20, want_operator=False,
                          out=None):

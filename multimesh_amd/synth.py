@@ -74,10 +74,50 @@ def quad_mesh(n: int, seed: int = 1, jitter: float = 0.2):
     return np.ascontiguousarray(pts), np.ascontiguousarray(base[:, None] + off[None, :])
 
 
+def gll_nodes_1d(order: int) -> np.ndarray:
+    """GLL nodes on [-1, 1] for the orders the reference supports (1, 2, 4)."""
+    if order == 1:
+        return np.array([-1.0, 1.0])
+    if order == 2:
+        return np.array([-1.0, 0.0, 1.0])
+    if order == 4:
+        a = np.sqrt(3.0 / 7.0)
+        return np.array([-1.0, -a, 0.0, a, 1.0])
+    raise ValueError("order must be 1, 2 or 4")
+
+
+def gll_mesh(n: int, order: int, seed: int = 1, jitter: float = 0.2, dim: int = 3):
+    """Element-nodal GLL mesh ``f64[nelem, (order+1)^dim, dim]`` (the layout of the reference's
+    ``MODEL/coordinates`` / ``mesh.points[mesh.connectivity]``): the control nodes of every element
+    of :func:`hex_mesh` / :func:`quad_mesh` placed by the (bi/tri)linear map of the tensor GLL
+    points, node index p = i + (order+1) j + (order+1)^2 k with the first reference axis fastest."""
+    g = gll_nodes_1d(order)
+    m = order + 1
+    if dim == 3:
+        pts, conn = hex_mesh(n, seed=seed, jitter=jitter)
+        v = pts[conn]                                  # exodus order corners [E, 8, 3]
+        corner = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1],
+                           [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=np.float64)
+        k_, j_, i_ = np.meshgrid(g, g, g, indexing="ij")  # p = i + m j + m^2 k
+        xi = np.stack([i_.ravel(), j_.ravel(), k_.ravel()], axis=1)            # [P, 3]
+        shape = np.prod(1.0 + xi[:, None, :] * corner[None, :, :], axis=2) / 8.0  # [P, 8]
+    elif dim == 2:
+        pts, conn = quad_mesh(n, seed=seed, jitter=jitter)
+        v = pts[conn]                                  # counter-clockwise corners [E, 4, 2]
+        corner = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=np.float64)
+        j_, i_ = np.meshgrid(g, g, indexing="ij")
+        xi = np.stack([i_.ravel(), j_.ravel()], axis=1)
+        shape = np.prod(1.0 + xi[:, None, :] * corner[None, :, :], axis=2) / 4.0
+    else:
+        raise ValueError("dim must be 2 or 3")
+    assert shape.shape[0] == m ** dim
+    return np.ascontiguousarray(np.einsum("pc,ecd->epd", shape, v))
+
+
 def field_linear(p: np.ndarray) -> np.ndarray:
     """f1 = 1 + 2x - 3y + 0.5z: reproduced exactly (to the Newton tolerance) by hex8."""
-    z = p[:, 2] if p.shape[1] > 2 else 0.0
-    return 1.0 + 2.0 * p[:, 0] - 3.0 * p[:, 1] + 0.5 * z
+    z = p[..., 2] if p.shape[-1] > 2 else 0.0
+    return 1.0 + 2.0 * p[..., 0] - 3.0 * p[..., 1] + 0.5 * z
 
 
 def field_smooth(p: np.ndarray) -> np.ndarray:
@@ -102,4 +142,5 @@ CONFIGS = {
     "cfg3": dict(n_src=216, n_tgt=216, ncomp=3),   # 10M -> 10M, vector field
     "metric": dict(n_src=216, n_tgt=216, ncomp=1),  # BASELINE.json metric: 10M -> 10M, 1 scalar
     "cfg4": dict(n_src=216, n_tgt=465, ncomp=1),   # 100M targets over 8 GPUs
+    # cfg5 (order-4 GLL hexes, 43^3 source / 47^3 target elements) is served by gll_mesh(44, 4) / (48, 4)
 }

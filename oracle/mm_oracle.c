@@ -11,10 +11,15 @@
  * reference's association order, because parity for the weights is judged
  * bit-for-bit; compile with -ffp-contract=off (see oracle/Makefile).
  *
- * Pinning: tests/test_oracle_pinned.py compares every function below with the
- * reference's own C translation units compiled into oracle/_ref/ (when
+ * Pinning: tests/test_oracle_pinned.py compares every hex8 function below with
+ * the reference's own C translation units compiled into oracle/_ref/ (when
  * /root/reference is present) and with the committed fixtures in
  * tests/golden/ that were generated from that build.
+ *
+ * The GLL section at the end (A10) is PARITY UNPINNED: its numerics live in the
+ * proprietary salvus.fem package the reference imports, which is absent and has
+ * no test or fixture in the reference; only its control flow follows the
+ * reference, and it is pinned by analytic properties (tests/test_gll_oracle.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -357,4 +362,231 @@ void mmo_knn_brute(const double *src, i64 nsrc, const double *pts, i64 npts,
     }
     free(bd);
     free(bi);
+}
+
+/* ================================================================== */
+/* A10: GLL elements (order 1, 2, 4; 2-D and 3-D).  PARITY UNPINNED:   */
+/* the reference obtains the inverse coordinate transform and the      */
+/* interpolation coefficients from the proprietary salvus.fem package  */
+/* (components/interpolator.py:22-57, :1337-1347, :1370-1386), which   */
+/* is not available; no reference test pins its results.  The CONTROL  */
+/* FLOW below follows the reference (interpolator.py:1181-1233); the   */
+/* NUMERICS are this project's own definition, shared verbatim with    */
+/* the HIP kernel (multimesh_amd/csrc/mm_locate_gll.hip):              */
+/*  - tensor-product Lagrange basis on the GLL nodes of [-1,1]         */
+/*    (order 1: -1,1; order 2: -1,0,1; order 4: -1,-sqrt(3/7),0,       */
+/*    sqrt(3/7),1), node index p = i + (n+1) j + (n+1)^2 k with xi_1   */
+/*    fastest;                                                         */
+/*  - Newton from xi = 0 on x(xi) = sum_p L_p(xi) X_p, Jacobian by the */
+/*    analytic basis derivatives, cofactor solve; converged when the   */
+/*    largest component of the update is < 1e-12; at most 25 updates;  */
+/*    NaN when the Jacobian is singular, an iterate leaves [-10,10]    */
+/*    or the iteration does not converge.                              */
+/* ================================================================== */
+static void gll_nodes(int order, double *g)
+{
+    if (order == 1) { g[0] = -1.0; g[1] = 1.0; }
+    else if (order == 2) { g[0] = -1.0; g[1] = 0.0; g[2] = 1.0; }
+    else { const double a = sqrt(3.0 / 7.0); g[0] = -1.0; g[1] = -a; g[2] = 0.0; g[3] = a; g[4] = 1.0; }
+}
+
+/* 1-D Lagrange values l[i] and derivatives dl[i] at x, straightforward product formulas with a
+ * fixed loop order (the HIP kernel uses the same). */
+static void lagrange_1d(int order, const double *g, double x, double *l, double *dl)
+{
+    const int n = order + 1;
+    for (int i = 0; i < n; ++i) {
+        double v = 1.0;
+        for (int m = 0; m < n; ++m)
+            if (m != i) v = v * ((x - g[m]) / (g[i] - g[m]));
+        l[i] = v;
+        double d = 0.0;
+        for (int m = 0; m < n; ++m) {
+            if (m == i) continue;
+            double t = 1.0 / (g[i] - g[m]);
+            for (int q = 0; q < n; ++q)
+                if (q != i && q != m) t = t * ((x - g[q]) / (g[i] - g[q]));
+            d = d + t;
+        }
+        dl[i] = d;
+    }
+}
+
+/* interpolation coefficients at xi (reference get_coefficients, interpolator.py:1337-1347) */
+void mmo_gll_coefficients(int order, int dim, const double *xi, double *coeffs)
+{
+    double g[5], l[3][5], dl[3][5];
+    const int n = order + 1;
+    gll_nodes(order, g);
+    for (int d = 0; d < dim; ++d) lagrange_1d(order, g, xi[d], l[d], dl[d]);
+    if (dim == 3) {
+        for (int k = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) coeffs[i + n * (j + n * k)] = (l[0][i] * l[1][j]) * l[2][k];
+    } else {
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) coeffs[i + n * j] = l[0][i] * l[1][j];
+    }
+}
+
+/* inverse coordinate transform (reference inverse_transform, interpolator.py:1370-1386): ctrl is
+ * the element's P control nodes [P][dim]; xi receives the reference coordinates or NaNs. */
+void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const double *ctrl, double *xi)
+{
+    double g[5], l[3][5], dl[3][5];
+    const int n = order + 1;
+    gll_nodes(order, g);
+    for (int d = 0; d < dim; ++d) xi[d] = 0.0;
+    for (int it = 0; it < 25; ++it) {
+        for (int d = 0; d < dim; ++d) lagrange_1d(order, g, xi[d], l[d], dl[d]);
+        double x[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (dim == 3) {
+            for (int k = 0; k < n; ++k)
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const double *X = ctrl + 3 * (i + n * (j + n * k));
+                        const double w = (l[0][i] * l[1][j]) * l[2][k];
+                        const double g0 = (dl[0][i] * l[1][j]) * l[2][k];
+                        const double g1 = (l[0][i] * dl[1][j]) * l[2][k];
+                        const double g2 = (l[0][i] * l[1][j]) * dl[2][k];
+                        for (int a = 0; a < 3; ++a) {
+                            x[a] = x[a] + w * X[a];
+                            J[a][0] = J[a][0] + g0 * X[a];
+                            J[a][1] = J[a][1] + g1 * X[a];
+                            J[a][2] = J[a][2] + g2 * X[a];
+                        }
+                    }
+        } else {
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) {
+                    const double *X = ctrl + 2 * (i + n * j);
+                    const double w = l[0][i] * l[1][j];
+                    const double g0 = dl[0][i] * l[1][j];
+                    const double g1 = l[0][i] * dl[1][j];
+                    for (int a = 0; a < 2; ++a) {
+                        x[a] = x[a] + w * X[a];
+                        J[a][0] = J[a][0] + g0 * X[a];
+                        J[a][1] = J[a][1] + g1 * X[a];
+                    }
+                }
+        }
+        double r[3] = {0, 0, 0}, dxi[3] = {0, 0, 0};
+        for (int a = 0; a < dim; ++a) r[a] = x[a] - pnt[a];
+        if (dim == 3) {
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+            const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+            const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            const double det = (J[0][0] * c00 + J[0][1] * c01) + J[0][2] * c02;
+            const double rdet = 1.0 / det;
+            /* inverse = adjugate / det; dxi = inverse * r */
+            const double i00 = c00 * rdet, i01 = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rdet,
+                         i02 = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rdet;
+            const double i10 = c01 * rdet, i11 = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rdet,
+                         i12 = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rdet;
+            const double i20 = c02 * rdet, i21 = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rdet,
+                         i22 = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rdet;
+            dxi[0] = (i00 * r[0] + i01 * r[1]) + i02 * r[2];
+            dxi[1] = (i10 * r[0] + i11 * r[1]) + i12 * r[2];
+            dxi[2] = (i20 * r[0] + i21 * r[1]) + i22 * r[2];
+        } else {
+            const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+            const double rdet = 1.0 / det;
+            dxi[0] = (J[1][1] * r[0] - J[0][1] * r[1]) * rdet;
+            dxi[1] = (J[0][0] * r[1] - J[1][0] * r[0]) * rdet;
+        }
+        double step = 0.0;
+        int bad = 0;
+        for (int a = 0; a < dim; ++a) {
+            xi[a] = xi[a] - dxi[a];
+            if (fabs(dxi[a]) > step) step = fabs(dxi[a]);
+            if (!(fabs(xi[a]) <= 10.0)) bad = 1; /* also catches NaN */
+        }
+        if (bad) break;
+        if (step < 1e-12) return;
+    }
+    for (int d = 0; d < dim; ++d) xi[d] = NAN;
+}
+
+/* Element search + coefficients, control flow of reference get_element_weights.check_inside
+ * (interpolator.py:1181-1233): walk the candidates in order; skip NaN results; remember the
+ * candidate with the smallest max|xi| (the first finite one always replaces the 10e9 start value);
+ * accept the first with all |xi| < tolerance; otherwise, with snap_to_nearest, clip the remembered
+ * xi to +-1.02 and use it, else element -1 and zero coefficients.
+ * gll_points [nelem][P][dim]; nn [npoints][k]; elem [npoints]; coeffs [npoints][P].
+ * Returns the number of points that got element -1. */
+i64 mmo_locate_gll(int order, int dim, i64 k, i64 npoints, const i64 *nn, const double *gll_points, i64 nelem,
+                   const double *points, double tolerance, int snap_to_nearest, i64 *elem, double *coeffs)
+{
+    int P = 1;
+    for (int d = 0; d < dim; ++d) P *= order + 1;
+    i64 missing = 0;
+    for (i64 i = 0; i < npoints; ++i) {
+        const double *pnt = points + i * dim;
+        double best_xi[3] = {10e9, 10e9, 10e9};
+        double best_val = 10e9;
+        i64 best_elem = 0;
+        int found = 0;
+        double xi[3];
+        for (i64 j = 0; j < k && !found; ++j) {
+            const i64 e = nn[i * k + j];
+            if (e < 0 || e >= nelem) continue;
+            mmo_gll_inverse_transform(order, dim, pnt, gll_points + (size_t)e * P * dim, xi);
+            int isnan_any = 0;
+            double worst = 0.0;
+            for (int d = 0; d < dim; ++d) {
+                if (xi[d] != xi[d]) isnan_any = 1;
+                if (fabs(xi[d]) > worst) worst = fabs(xi[d]);
+            }
+            if (isnan_any) continue;
+            if (worst < best_val) {
+                best_val = worst;
+                best_elem = e;
+                for (int d = 0; d < dim; ++d) best_xi[d] = xi[d];
+            }
+            int inside = 1;
+            for (int d = 0; d < dim; ++d)
+                if (!(fabs(xi[d]) < tolerance)) inside = 0;
+            if (inside) {
+                elem[i] = e;
+                mmo_gll_coefficients(order, dim, xi, coeffs + i * P);
+                found = 1;
+            }
+        }
+        if (found) continue;
+        if (snap_to_nearest) {
+            for (int d = 0; d < dim; ++d) {
+                double v = best_xi[d];
+                if (v < -1.02) v = -1.02;
+                if (v > 1.02) v = 1.02;
+                best_xi[d] = v;
+            }
+            elem[i] = best_elem;
+            mmo_gll_coefficients(order, dim, best_xi, coeffs + i * P);
+        } else {
+            elem[i] = -1;
+            for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+            missing += 1;
+        }
+    }
+    return missing;
+}
+
+/* Element-nodal gather: np.sum(coeffs * field[elem_indices], axis=1) (reference
+ * interpolator.py:976); field [ncomp][nelem][P]; element -1 contributes zeros. */
+int mmo_gather_elem(const double *field, i64 nelem, i64 ncomp, const i64 *elem, const double *coeffs, i64 npoints,
+                    i64 P, double *out, int out_point_major)
+{
+    if (P > 128) return -1;
+    double prod[128];
+    for (i64 c = 0; c < ncomp; ++c) {
+        const double *f = field + c * nelem * P;
+        for (i64 i = 0; i < npoints; ++i) {
+            const i64 e = elem[i] >= 0 && elem[i] < nelem ? elem[i] : 0;
+            for (i64 p = 0; p < P; ++p) prod[p] = coeffs[i * P + p] * f[e * P + p];
+            const double v = numpy_row_sum(prod, P);
+            if (out_point_major) out[i * ncomp + c] = v;
+            else out[c * npoints + i] = v;
+        }
+    }
+    return 0;
 }

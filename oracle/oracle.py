@@ -64,6 +64,16 @@ def lib():
         L.mmo_hex8_newton.argtypes = [_f64p, _f64p, _f64p, C.POINTER(C.c_int)]
         L.mmo_hex8_weights.restype = None
         L.mmo_hex8_weights.argtypes = [_f64p, _f64p]
+        L.mmo_gll_coefficients.restype = None
+        L.mmo_gll_coefficients.argtypes = [C.c_int, C.c_int, _f64p, _f64p]
+        L.mmo_gll_inverse_transform.restype = None
+        L.mmo_gll_inverse_transform.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f64p]
+        L.mmo_locate_gll.restype = C.c_int64
+        L.mmo_locate_gll.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _f64p, C.c_int64, _f64p,
+                                     C.c_double, C.c_int, _i64p, _f64p]
+        L.mmo_gather_elem.restype = C.c_int
+        L.mmo_gather_elem.argtypes = [_f64p, C.c_int64, C.c_int64, _i64p, _f64p, C.c_int64, C.c_int64, _f64p,
+                                      C.c_int]
         _cache["o"] = L
     return _cache["o"]
 
@@ -139,6 +149,53 @@ def knn_brute(src, pts, k, want_d2=False):
     lib().mmo_knn_brute(src, src.shape[0], pts, pts.shape[0], src.shape[1], k, idx,
                         d2.ctypes.data_as(C.c_void_p))
     return (idx, d2) if want_d2 else idx
+
+
+# ----------------------------------------------------------------------------- GLL (parity unpinned)
+def gll_coefficients(order, xi):
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    dim = xi.shape[0]
+    out = np.zeros((order + 1) ** dim)
+    lib().mmo_gll_coefficients(order, dim, xi, out)
+    return out
+
+
+def gll_inverse_transform(order, pnt, ctrl):
+    pnt = np.ascontiguousarray(pnt, dtype=np.float64)
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+    xi = np.zeros(pnt.shape[0])
+    lib().mmo_gll_inverse_transform(order, pnt.shape[0], pnt, ctrl, xi)
+    return xi
+
+
+def locate_gll(order, nn, gll_points, points, tolerance=1.05, snap_to_nearest=False):
+    """Control flow of reference interpolator.py:1181-1233 -> (elem int64[N], coeffs f64[N,P], nmissing)."""
+    nn = np.ascontiguousarray(nn, dtype=np.int64)
+    gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    nelem, P, dim = gll_points.shape
+    n, k = nn.shape
+    elem = np.zeros(n, dtype=np.int64)
+    coeffs = np.zeros((n, P))
+    miss = lib().mmo_locate_gll(order, dim, k, n, nn, gll_points, nelem, points, tolerance,
+                                1 if snap_to_nearest else 0, elem, coeffs)
+    return elem, coeffs, int(miss)
+
+
+def gather_elem(fields, elem, coeffs, point_major=True):
+    """fields f64[C, E, P] (or [E, P]) -> np.sum(coeffs * field[elem], axis=1) per component."""
+    fields = np.ascontiguousarray(fields, dtype=np.float64)
+    if fields.ndim == 2:
+        fields = fields[None]
+    ncomp, nelem, P = fields.shape
+    elem = np.ascontiguousarray(elem, dtype=np.int64)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    n = elem.shape[0]
+    out = np.zeros((n, ncomp) if point_major else (ncomp, n))
+    rc = lib().mmo_gather_elem(fields, nelem, ncomp, elem, coeffs, n, P, out, 1 if point_major else 0)
+    if rc != 0:
+        raise ValueError("P > 128 unsupported")
+    return out
 
 
 # ----------------------------------------------------------------------------- third party

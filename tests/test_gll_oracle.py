@@ -1,0 +1,120 @@
+"""SURVEY.md §8 row A10 is PARITY UNPINNED (the reference's GLL numerics live in the absent,
+proprietary salvus.fem and no reference test pins them).  These tests pin our own definition
+(oracle/mm_oracle.c "A10" == multimesh_amd/csrc/mm_locate_gll.hip) by analytic properties:
+partition of unity, Kronecker property, polynomial reproduction up to the element order,
+inverse-transform round trip, control flow of the reference's acceptance loop, and
+order-1 GLL == the (reference-pinned) hex8 path."""
+import numpy as np
+import pytest
+
+from multimesh_amd import synth
+from oracle import oracle as O
+
+CASES = [(o, d) for o in (1, 2, 4) for d in (2, 3)]
+
+
+@pytest.mark.parametrize("order,dim", CASES)
+def test_coefficients_partition_of_unity_and_kronecker(order, dim):
+    g = synth.gll_nodes_1d(order)
+    rng = np.random.default_rng(order * 10 + dim)
+    for _ in range(50):
+        xi = rng.uniform(-1.05, 1.05, size=dim)
+        assert abs(O.gll_coefficients(order, xi).sum() - 1) < 1e-13
+    m = order + 1
+    for p in range(m ** dim):
+        idx = [(p // m ** a) % m for a in range(dim)]
+        c = O.gll_coefficients(order, g[idx])
+        e = np.zeros(m ** dim)
+        e[p] = 1
+        assert np.abs(c - e).max() < 1e-14
+
+
+@pytest.mark.parametrize("order,dim", CASES)
+def test_polynomials_up_to_the_order_are_reproduced(order, dim):
+    # in reference coordinates every monomial xi^a * eta^b * ... with exponents <= order is in the basis
+    g = synth.gll_nodes_1d(order)
+    rng = np.random.default_rng(3)
+    grids = np.meshgrid(*([g] * dim), indexing="ij")
+    nodes = np.stack([gr.T.ravel() if dim == 2 else gr.transpose(2, 1, 0).ravel() for gr in grids], axis=1)
+    # node p = i + m j (+ m^2 k): first axis fastest
+    for _ in range(20):
+        expo = rng.integers(0, order + 1, size=dim)
+        xi = rng.uniform(-1, 1, size=dim)
+        nodal = np.prod(nodes ** expo, axis=1)
+        got = O.gll_coefficients(order, xi) @ nodal
+        assert abs(got - np.prod(xi ** expo)) < 1e-12
+
+
+@pytest.mark.parametrize("order,dim", CASES)
+def test_inverse_transform_round_trip_and_failure(order, dim):
+    gp = synth.gll_mesh(4, order, seed=5, jitter=0.3, dim=dim)
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        e = rng.integers(0, gp.shape[0])
+        xi = rng.uniform(-1.02, 1.02, size=dim)
+        x = O.gll_coefficients(order, xi) @ gp[e]
+        back = O.gll_inverse_transform(order, x, gp[e])
+        assert np.abs(back - xi).max() < 1e-10
+    far = O.gll_inverse_transform(order, np.full(dim, 50.0), gp[0])     # way outside: diverges -> NaN
+    assert np.isnan(far).all()
+    flat = np.zeros_like(gp[0])                                           # degenerate element: singular Jacobian
+    assert np.isnan(O.gll_inverse_transform(order, np.full(dim, 0.1), flat)).all()
+
+
+@pytest.mark.parametrize("order,dim", CASES)
+def test_locate_and_gather_reproduce_smooth_fields(order, dim):
+    gp = synth.gll_mesh(6, order, seed=2, dim=dim)
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(0.0, 1.0, size=(800, dim))
+    nn, _ = O.knn_ckdtree(gp.mean(axis=1), pts, min(25, gp.shape[0]))
+    elem, co, miss = O.locate_gll(order, nn, gp, pts)
+    assert miss == 0 and (elem >= 0).all()
+    assert np.abs(co.sum(axis=1) - 1).max() < 1e-12
+    lin = O.gather_elem(synth.field_linear(gp), elem, co)[:, 0]
+    assert np.abs(lin - synth.field_linear(pts)).max() < 1e-12              # any order reproduces linear fields
+    smooth_err = np.abs(O.gather_elem(synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2]), elem, co)[:, 0]
+                        - synth.field_smooth(pts)).max()
+    assert smooth_err < {1: 0.8, 2: 0.12, 4: 3e-3}[order]                  # error falls fast with the order
+    # literal NumPy statement of reference interpolator.py:976
+    f = synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2])
+    assert np.array_equal(O.gather_elem(f, elem, co)[:, 0], np.sum(co * f[elem], axis=1))
+
+
+def test_control_flow_not_found_snap_and_tolerance():
+    gp = synth.gll_mesh(4, 2, seed=1, dim=3)
+    cen = gp.mean(axis=1)
+    pts = np.array([[0.5, 0.5, 0.5], [1.005, 0.5, 0.5], [1.5, 0.5, 0.5], [-0.3, -0.3, -0.3]])  # xi_x = 1.03 for #1
+    nn, _ = O.knn_ckdtree(cen, pts, 25)
+    elem, co, miss = O.locate_gll(2, nn, gp, pts, tolerance=1.05, snap_to_nearest=False)
+    assert elem[0] >= 0 and elem[1] >= 0 and elem[2] == -1 and elem[3] == -1 and miss == 2
+    assert not co[2].any() and not co[3].any()                             # reference: (-1, zeros)
+    elem_s, co_s, miss_s = O.locate_gll(2, nn, gp, pts, tolerance=1.05, snap_to_nearest=True)
+    assert miss_s == 0 and (elem_s >= 0).all()
+    assert np.abs(co_s.sum(axis=1) - 1).max() < 1e-12                      # clipped xi still a partition of unity
+    # a tighter tolerance (the layered variant uses 1.03) can only lose points: #1 drops out at 1.0
+    _, _, miss_t = O.locate_gll(2, nn, gp, pts, tolerance=1.0, snap_to_nearest=False)
+    assert miss_t == 3
+    # padded / invalid candidates are skipped
+    bad = np.concatenate([np.full((len(pts), 1), gp.shape[0] + 5), nn[:, :-1]], axis=1)
+    elem_b, _, _ = O.locate_gll(2, bad, gp, pts)
+    assert elem_b[0] == elem[0]
+
+
+def test_order1_gll_equals_reference_pinned_hex8_path():
+    # same element found and same interpolated values as the hex8 path (whose oracle IS pinned)
+    pa, ca = synth.hex_mesh(7, seed=1)
+    gp = synth.gll_mesh(7, 1, seed=1, dim=3)
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(0.05, 0.95, size=(600, 3))
+    cen = O.centroid(ca, pa)
+    assert np.abs(cen - gp.mean(axis=1)).max() < 1e-15
+    nn, _ = O.knn_ckdtree(cen, pts, 20)
+    enc, w, nf = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pts)
+    elem, co, miss = O.locate_gll(1, nn, gp, pts, tolerance=1.025)
+    assert nf == 0 and miss == 0
+    f_nodal = synth.field_smooth(pa)
+    v_hex = O.gather(f_nodal, enc, w)[:, 0]
+    v_gll = O.gather_elem(synth.field_smooth(gp.reshape(-1, 3)).reshape(gp.shape[:2]), elem, co)[:, 0]
+    assert np.abs(v_hex - v_gll).max() < 1e-7                               # hex8 Newton stops at 1e-8 * scale
+    # both found the element whose 8 corners are the hex8 row's node set
+    assert all(set(enc[i]) == set(ca[elem[i]]) for i in range(len(pts)))

@@ -235,3 +235,46 @@ def test_cfg2_1M_to_1M(ctx):
 
 def test_cfg3_10M_to_10M_vector_field(ctx):
     _full_size_check(ctx, 216, 216, 3, sample=20_000)
+
+
+# ------------------------------------------------------------------------------- A10 GLL (parity unpinned)
+@pytest.mark.parametrize("order,dim", [(o, d) for o in (1, 2, 4) for d in (2, 3)])
+def test_gll_locate_and_gather_equal_the_oracle(ctx, order, dim):
+    # our own numerics (the reference's live in the absent salvus.fem): kernel == oracle bit for bit
+    gp = synth.gll_mesh(7 if dim == 3 else 12, order, seed=4, jitter=0.25, dim=dim)
+    rng = np.random.default_rng(order + dim)
+    pts = rng.uniform(-0.03, 1.03, size=(3000, dim))                # some outside -> -1 / snapped
+    cen = gp.mean(axis=1)
+    k = min(25, gp.shape[0])
+    nn = ctx.knn_build(cen).query(pts, k).numpy()
+    assert np.array_equal(nn, O.knn_ckdtree(cen, pts, k)[0])
+    fields = np.stack([synth.field_linear(gp), synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2])])
+    for tol, snap in ((1.05, False), (1.03, False), (1.05, True)):
+        elem, co, miss = ctx.locate_gll(order, nn, gp, pts, tolerance=tol, snap_to_nearest=snap)
+        elem_o, co_o, miss_o = O.locate_gll(order, nn, gp, pts, tolerance=tol, snap_to_nearest=snap)
+        assert miss == miss_o and (snap or miss > 0)
+        assert np.array_equal(elem.numpy(), elem_o)
+        assert np.array_equal(co.numpy(), co_o)
+        vals = ctx.gather_elem(fields, elem, co).numpy()
+        assert np.array_equal(vals, O.gather_elem(fields, elem_o, co_o))
+        assert np.array_equal(ctx.gather_elem(fields, elem, co, point_major=False).numpy(), vals.T)
+        found = elem_o >= 0
+        assert np.abs(vals[found, 0] - synth.field_linear(pts[found])).max() < 1e-11 or snap
+
+
+def test_gll_api_and_cfg5_shaped_run(ctx):
+    # order-4 hexes as in cfg5 (reduced size): targets = the unique GLL points of a second mesh
+    from multimesh_amd import api
+
+    src = synth.gll_mesh(9, 4, seed=1, dim=3)                       # 8^3 elements x 125 nodes
+    tgt = np.unique(synth.gll_mesh(8, 4, seed=7, dim=3).reshape(-1, 3), axis=0)   # reference utils.py:484-488
+    mesh = api.GllMesh(src, 4, {"VP": synth.field_smooth(src.reshape(-1, 3)).reshape(src.shape[:2]),
+                                "RHO": synth.field_linear(src)})
+    vals = api.interpolate_gll_to_points(mesh, tgt, ["VP", "RHO"], nelem_to_search=20, tolerance=1.05)
+    assert vals.shape == (len(tgt), 2)
+    assert np.abs(vals[:, 1] - synth.field_linear(tgt)).max() < 1e-11
+    assert np.abs(vals[:, 0] - synth.field_smooth(tgt)).max() < 2e-3
+    elems, coeffs = api.get_element_weights(src, 4, src.mean(axis=1), tgt, nelem_to_search=20)
+    nn, _ = O.knn_ckdtree(src.mean(axis=1), tgt, 20)
+    elem_o, co_o, _ = O.locate_gll(4, nn, src, tgt)
+    assert np.array_equal(elems, elem_o) and np.array_equal(coeffs, co_o)
