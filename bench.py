@@ -233,6 +233,16 @@ def main():
             "roofline": roofline,
             "stages": stages,
         }
+        if world == 1:
+            # PCIe-inclusive rate (never `value`): the same step fed from HOST arrays, i.e. what the
+            # legacy host-pointer boundary costs: H2D of mesh + targets + field, D2H of the result
+            t0 = time.perf_counter()
+            vals_h, _ = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=k)
+            vals_h = vals_h.numpy()
+            t_host = time.perf_counter() - t0
+            line["host_arrays"] = {"ms": t_host * 1e3, "points_per_s": n_local / t_host,
+                                   "note": "one step fed from pageable host arrays (H2D + kernels + D2H); not `value`"}
+            del vals_h
         if world == 1 and not args.no_cpu_baseline:
             stride = args.cpu_sample_stride or max(1, n_local // 1_000_000)
             base, (stride, enc_c, w_c, vals_c) = cpu_baseline(pa, ca, pb, fields, k, stride)
