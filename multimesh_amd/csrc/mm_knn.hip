@@ -295,10 +295,24 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
         const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
         const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+        // k-th best so far: cells farther than that cannot contribute (only prunes once the list
+        // is full, i.e. from the second ring on; equal distances are NOT pruned: ties go by index)
+        double kth_now = best.d[K - 1];
+        if (kout < K) {
+#pragma unroll
+            for (int s = 0; s < K - 1; ++s)
+                if (s == kout - 1) kth_now = best.d[s];
+        }
         for (int ix = x0; ix <= x1; ++ix) {
             const int adx = abs(ix - cx);
+            const double cxl = g.lox + (double)ix * g.hx;
+            const double ddx = fmax(fmax(cxl - px, px - (cxl + g.hx)) - 1e-9 * g.hx, 0.0);
             for (int iy = y0; iy <= y1; ++iy) {
                 const int ady = abs(iy - cy);
+                const double cyl = g.loy + (double)iy * g.hy;
+                const double ddy = fmax(fmax(cyl - py, py - (cyl + g.hy)) - 1e-9 * g.hy, 0.0);
+                const double lat2 = ddx * ddx + ddy * ddy;
+                if (lat2 > kth_now) continue;
                 const int col = (ix * g.ny + iy) * g.nz;
                 // columns outside the previous block take the whole z range; inner columns only
                 // the two new caps [cz-R, cz-rprev-1] and [cz+rprev+1, cz+R]
@@ -317,6 +331,9 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
                         zb = z1;
                     }
                     if (za > zb) continue;
+                    const double zl = g.loz + (double)za * g.hz, zh = g.loz + (double)(zb + 1) * g.hz;
+                    const double ddz = fmax(fmax(zl - pz, pz - zh) - 1e-9 * g.hz, 0.0);
+                    if (lat2 + ddz * ddz > kth_now) continue;
                     const int s0 = cell_start[col + za];
                     const int s1 = cell_start[col + zb + 1];
                     for (int s = s0; s < s1; ++s) {
@@ -1074,6 +1091,13 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
     else if (k <= 25) launch_fast<25>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
     else launch_fast<32>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
     MM_HIP_CHECK(hipGetLastError());
+    if (getenv("MM_KNN_DEBUG")) {
+        int h = 0;
+        MM_HIP_CHECK(hipMemcpyAsync(&h, fb_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[mm_knn] %d of %lld targets handed to the generic kernel (%.2f %%)\n", h, (long long)npts,
+                100.0 * h / (double)npts);
+    }
     return MM_OK;
 }
 

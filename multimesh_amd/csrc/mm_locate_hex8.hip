@@ -278,75 +278,114 @@ constexpr int kPassIters = 10;
 
 // One compacting pass (see "Scheduling" in the header comment).  q_in == null: the open set is
 // every target, starting at candidate 0.
+//
+// Re-queueing.  A single device-scope counter serves only ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md, "dequeue"), and in the first pass nearly every wave has something to
+// re-queue: one atomic per wave per tile would serialise ~1.8 ms on that word.  So the waves are
+// persistent (grid-stride over tiles) and each wave batches its entries in LDS (slot = ballot
+// prefix, no atomics), reserving queue space with ONE global atomic per ~200 entries and writing
+// them out as coalesced 8-byte stores.
+constexpr int kPassBlock = 256;
+constexpr int kWaveQueue = 256;   // LDS entries per wave; flushed when more than kWaveQueue - 64 are held
+
 template <bool EXODUS>
-__global__ __launch_bounds__(256) void locate_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
-                                                          const i64 *__restrict__ conn, i64 nelem,
-                                                          i64 *__restrict__ enc, const double *__restrict__ nodes,
-                                                          double *__restrict__ w, const double *__restrict__ pts,
-                                                          const int2 *__restrict__ q_in,
-                                                          const int *__restrict__ q_in_count,
-                                                          int2 *__restrict__ q_out, int *__restrict__ q_out_count,
-                                                          int *__restrict__ slow_list, int *__restrict__ slow_count)
+__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+                                                                 const i64 *__restrict__ conn, i64 nelem,
+                                                                 i64 *__restrict__ enc,
+                                                                 const double *__restrict__ nodes,
+                                                                 double *__restrict__ w,
+                                                                 const double *__restrict__ pts,
+                                                                 const int2 *__restrict__ q_in,
+                                                                 const int *__restrict__ q_in_count,
+                                                                 int2 *__restrict__ q_out,
+                                                                 int *__restrict__ q_out_count,
+                                                                 int *__restrict__ slow_list,
+                                                                 int *__restrict__ slow_count)
 {
+    __shared__ int2 s_queue[kPassBlock / 64][kWaveQueue];
+    const int lane = threadIdx.x & 63;
+    int2 *my_queue = s_queue[threadIdx.x >> 6];
+    int held = 0;  // wave-uniform: entries waiting in my_queue
+
     const i64 total = q_in ? (i64)*q_in_count : npoints;
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        i64 i;
-        int j;
-        if (q_in) {
-            const int2 e = q_in[q];
-            i = e.x;
-            j = e.y;
-        } else {
-            i = q;
-            j = 0;
+    const i64 first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    // every lane runs the same number of trips so that the ballots below are wave-wide
+    const i64 trips = (total + stride - 1) / stride;
+    for (i64 trip = 0; trip < trips; ++trip) {
+        const i64 q = first + trip * stride;
+        const bool active = q < total;
+        i64 i = 0;
+        int j = 0;
+        if (active) {
+            if (q_in) {
+                const int2 e = q_in[q];
+                i = e.x;
+                j = e.y;
+            } else {
+                i = q;
+            }
         }
-        const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
-        Corners c;
-        // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point
-        bool have = false;
-        for (; j < k; ++j) {
-            const i64 elem = nn[i * k + j];
-            if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
-            load_corners<EXODUS>(conn, nodes, elem, c);
-            double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
+        bool requeue = false;
+        if (active) {
+            const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+            Corners c;
+            // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point
+            bool have = false;
+            for (; j < k; ++j) {
+                const i64 elem = nn[i * k + j];
+                if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
+                load_corners<EXODUS>(conn, nodes, elem, c);
+                double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
 #pragma unroll
-            for (int n = 1; n < 8; ++n) {
-                xlo = fmin(xlo, c.x[n]);
-                xhi = fmax(xhi, c.x[n]);
-                ylo = fmin(ylo, c.y[n]);
-                yhi = fmax(yhi, c.y[n]);
+                for (int n = 1; n < 8; ++n) {
+                    xlo = fmin(xlo, c.x[n]);
+                    xhi = fmax(xhi, c.x[n]);
+                    ylo = fmin(ylo, c.y[n]);
+                    yhi = fmax(yhi, c.y[n]);
+                }
+                const double mx = 0.05 * (xhi - xlo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+                const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+                // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
+                const bool outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
+                if (!outside) {
+                    have = true;
+                    break;
+                }
             }
-            const double mx = 0.05 * (xhi - xlo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
-            const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
-            // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
-            const bool outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
-            if (!outside) {
-                have = true;
-                break;
+            if (!have) {
+                // no candidate left that could be accepted: fallback / failure is the reference's call
+                slow_list[atomicAdd(slow_count, 1)] = (int)i;
+            } else {
+                double xi[3], wt[8];
+                bool accepted = false;
+                // A solve that has not converged within kPassIters iterations (p99 is 6) would hold
+                // the whole wave for up to 50: such a target is handed to the reference-order kernel
+                // instead, where slow solves only keep each other company.
+                const bool converged = newton_hex8<kPassIters>(px, py, pz, c.x, c.y, c.z, xi);
+                if (converged && in_hull(xi)) {
+                    if (max_abs3(xi) < (1 + 0.025)) {
+                        weights_hex8(xi, wt);
+                        store_row(enc, w, i, c, wt);
+                        accepted = true;
+                    }
+                }
+                if (!accepted) {
+                    if (converged && j + 1 < k) requeue = true;
+                    else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+                }
             }
         }
-        if (!have) {
-            // no candidate left that could be accepted: fallback / failure is the reference's call
-            slow_list[atomicAdd(slow_count, 1)] = (int)i;
-            continue;
-        }
-        double xi[3], wt[8];
-        bool accepted = false;
-        // A solve that has not converged within kPassIters iterations (p99 is 6) would hold the
-        // whole wave for up to 50: such a target is handed to the reference-order kernel instead,
-        // where slow solves only keep each other company.
-        const bool converged = newton_hex8<kPassIters>(px, py, pz, c.x, c.y, c.z, xi);
-        if (converged && in_hull(xi)) {
-            if (max_abs3(xi) < (1 + 0.025)) {
-                weights_hex8(xi, wt);
-                store_row(enc, w, i, c, wt);
-                accepted = true;
-            }
-        }
-        if (!accepted) {
-            if (converged && j + 1 < k) q_out[atomicAdd(q_out_count, 1)] = make_int2((int)i, j + 1);
-            else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+        // batch the re-queue entries of this wave in LDS
+        const unsigned long long vote = __ballot(requeue);
+        if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j + 1);
+        held += __popcll(vote);
+        if (held > kWaveQueue - 64 || (trip == trips - 1 && held > 0)) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(q_out_count, held);
+            base = __shfl(base, 0);
+            for (int t = lane; t < held; t += 64) q_out[base + t] = my_queue[t];
+            held = 0;
         }
     }
 }
@@ -395,9 +434,10 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, co
         int2 *q_out = (p & 1) ? qb : qa;
         const int *q_in_count = p == 0 ? nullptr : counters + p;
         int *q_out_count = counters + p + 1;
-        // pass 0 covers every target; later passes only know their size on the device, so they
-        // run a bounded grid with a grid-stride loop (the open set shrinks ~3x per pass)
-        i64 grid = p == 0 ? full_grid : (full_grid >> (p < 4 ? p : 4));
+        // persistent waves (see "Re-queueing" above): a bounded grid with a grid-stride loop; later
+        // passes only know their size on the device (the open set shrinks ~3x per pass)
+        i64 grid = full_grid >> (p < 4 ? p : 4);
+        if (grid > 4096) grid = 4096;
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)grid), b(block);
         if (p == 0) mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
