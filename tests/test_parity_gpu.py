@@ -278,3 +278,63 @@ def test_gll_api_and_cfg5_shaped_run(ctx):
     nn, _ = O.knn_ckdtree(src.mean(axis=1), tgt, 20)
     elem_o, co_o, _ = O.locate_gll(4, nn, src, tgt)
     assert np.array_equal(elems, elem_o) and np.array_equal(coeffs, co_o)
+
+
+# ------------------------------------------------------------------------------- kNN regimes
+def test_knn_many_targets_per_cell_multi_round(ctx):
+    # ~60 targets per grid cell: several rounds per wave at the narrowest group split
+    rng = np.random.default_rng(11)
+    src = rng.uniform(size=(20_000, 3))
+    q = rng.uniform(size=(150_000, 3))
+    assert np.array_equal(ctx.knn_build(src).query(q, 20).numpy(), O.knn_ckdtree(src, q, 20, workers=-1)[0])
+
+
+def test_knn_few_targets_wide_groups(ctx):
+    # far fewer targets than cells: one target per wave, all 64 lanes on it
+    rng = np.random.default_rng(12)
+    src = rng.uniform(size=(300_000, 3))
+    q = rng.uniform(-0.1, 1.1, size=(500, 3))
+    for k in (1, 7, 20, 32):
+        assert np.array_equal(ctx.knn_build(src).query(q, k).numpy(), O.knn_ckdtree(src, q, k, workers=-1)[0])
+
+
+def test_knn_clustered_sources_overflow_the_tile(ctx):
+    # a tight cluster inside a sparse cloud: cells holding hundreds of sources (tile overflow ->
+    # generic kernel) next to nearly empty ones (ring expansion)
+    rng = np.random.default_rng(13)
+    src = np.concatenate([rng.normal(0.3, 0.004, size=(30_000, 3)), rng.uniform(size=(30_000, 3))])
+    q = np.concatenate([rng.normal(0.3, 0.01, size=(3_000, 3)), rng.uniform(size=(3_000, 3))])
+    assert np.array_equal(ctx.knn_build(src).query(q, 20).numpy(), O.knn_ckdtree(src, q, 20, workers=-1)[0])
+
+
+def test_knn_duplicate_sources_tie_overflow(ctx):
+    # every source repeated 40 times: far more exact ties than the collect list holds; the result
+    # must still be the (distance, index)-ordered truth
+    rng = np.random.default_rng(14)
+    base = rng.uniform(size=(600, 3))
+    src = np.repeat(base, 40, axis=0)
+    q = rng.uniform(size=(400, 3))
+    assert np.array_equal(ctx.knn_build(src).query(q, 20).numpy(), O.knn_brute(src, q, 20))
+
+
+def test_knn_2d_mesh_like_cfg1(ctx):
+    # cfg1: 2-D 100x100-node quad meshes (the reference runs this one on the CPU through cKDTree)
+    pa, ca = synth.quad_mesh(100, seed=1)
+    pb, _ = synth.quad_mesh(100, seed=7)
+    cen = O.centroid(ca, pa)
+    assert np.array_equal(ctx.centroid(ca, pa).numpy(), cen)
+    assert np.array_equal(ctx.knn_build(cen).query(pb, 20).numpy(), O.knn_ckdtree(cen, pb, 20)[0])
+
+
+def test_fused_pipeline_random_order_and_outside_targets(ctx):
+    # targets in random order (no spatial coherence) with a shell outside the hull
+    pa, ca = synth.hex_mesh(31, seed=1)
+    rng = np.random.default_rng(15)
+    pb = rng.uniform(-0.04, 1.04, size=(120_000, 3))
+    fields = synth.vector_field(pa)
+    vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, want_operator=True)
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+    assert nf == nf_o and nf > 0
+    assert np.array_equal(enc.numpy(), enc_o) and np.array_equal(w.numpy(), w_o)
+    assert np.array_equal(vals.numpy(), O.gather(fields, enc_o, w_o))
