@@ -46,7 +46,6 @@ enum mm_buffer_slot {
     MM_BUF_W,
     MM_BUF_CELL_START,
     MM_BUF_SORTED_XYZ,
-    MM_BUF_SORTED_ID,
     MM_BUF_COUNT
 };
 
@@ -100,7 +99,6 @@ struct mm_knn_index {
     double inv_h[3] = {1, 1, 1};
     i64 ncells = 1;
     int *cell_start = nullptr;     // [ncells + 1] exclusive prefix of per-cell counts
-    double *sorted_xyz = nullptr;  // [nsrc][3] source coordinates in cell order (z padded 0)
-    int *sorted_id = nullptr;      // [nsrc] original index of each sorted source
+    double *sorted_xyz = nullptr;  // [nsrc][4] records {x, y, z, original index bits} in cell order
     bool borrowed = false;         // arrays belong to the context's buffer cache (fused pipeline)
 };

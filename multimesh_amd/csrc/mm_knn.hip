@@ -105,7 +105,7 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
 }
 
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
-                                                            GridParams g, int *__restrict__ cell_of,
+                                                            GridParams g, int2 *__restrict__ cell_of,
                                                             int *__restrict__ counts)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,8 +117,9 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__rest
     const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
     const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
     const int c = (cx * g.ny + cy) * g.nz + cz;
-    cell_of[e] = c;
-    atomicAdd(&counts[c], 1);
+    // the histogram atomic also hands out the item's rank inside its cell, so the scatter pass
+    // needs no second atomic
+    cell_of[e] = make_int2(c, atomicAdd(&counts[c], 1));
 }
 
 // ---- exclusive scan of the per-cell counts (three small kernels) --------------------
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void scan_tile_offsets_kernel(int *__restri
 
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int *__restrict__ counts, i64 n,
                                                             const int *__restrict__ tile_offsets,
-                                                            int *__restrict__ start, int *__restrict__ cursor)
+                                                            int *__restrict__ start)
 {
     const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
     int v[kScanItems];
@@ -193,7 +194,6 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int *__restric
     for (int i = 0; i < kScanItems; ++i) {
         if (base + i < n) {
             start[base + i] = excl;
-            cursor[base + i] = excl;
         }
         excl += v[i];
     }
@@ -201,19 +201,30 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int *__restric
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) start[n] = excl;
 }
 
+// Sorted records are 32 bytes {x, y, z, original index (as the bits of a double)}: an item is
+// written with two 16-byte stores into its own aligned sector and read back the same way.
+constexpr int kRec = 4;
+
+__device__ __forceinline__ void store_record(double *__restrict__ rec, double x, double y, double z, int id)
+{
+    double2 *r2 = reinterpret_cast<double2 *>(rec);
+    r2[0] = make_double2(x, y);
+    r2[1] = make_double2(z, __longlong_as_double((long long)id));
+}
+
+__device__ __forceinline__ int record_id(double w) { return (int)__double_as_longlong(w); }
+
 __global__ __launch_bounds__(kBlock) void cell_scatter_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
-                                                              const int *__restrict__ cell_of,
-                                                              int *__restrict__ cursor,
-                                                              double *__restrict__ sorted_xyz,
-                                                              int *__restrict__ sorted_id)
+                                                              const int2 *__restrict__ cell_of,
+                                                              const int *__restrict__ start,
+                                                              double *__restrict__ sorted_rec)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nsrc) return;
-    const int pos = atomicAdd(&cursor[cell_of[e]], 1);
-    sorted_xyz[(i64)pos * 3 + 0] = src[e * ndim];
-    sorted_xyz[(i64)pos * 3 + 1] = ndim > 1 ? src[e * ndim + 1] : 0.0;
-    sorted_xyz[(i64)pos * 3 + 2] = ndim > 2 ? src[e * ndim + 2] : 0.0;
-    sorted_id[pos] = (int)e;
+    const int2 cr = cell_of[e];
+    const i64 pos = (i64)start[cr.x] + cr.y;
+    store_record(sorted_rec + pos * kRec, src[e * ndim], ndim > 1 ? src[e * ndim + 1] : 0.0,
+                 ndim > 2 ? src[e * ndim + 2] : 0.0, (int)e);
 }
 
 // ---- query --------------------------------------------------------------------------
@@ -276,7 +287,7 @@ __device__ __forceinline__ double block_bound(const GridParams &g, double px, do
 template <int K>
 __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, const int *__restrict__ cell_start,
                                               const double *__restrict__ sorted_xyz,
-                                              const int *__restrict__ sorted_id, const double *__restrict__ pts,
+                                              const double *__restrict__ pts,
                                               int ndim, int kout, i64 *__restrict__ idx_out,
                                               double *__restrict__ dist_out, i64 i)
 {
@@ -337,13 +348,15 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
                     const int s0 = cell_start[col + za];
                     const int s1 = cell_start[col + zb + 1];
                     for (int s = s0; s < s1; ++s) {
-                        const double dx = sorted_xyz[(i64)s * 3 + 0] - px;
-                        const double dy = sorted_xyz[(i64)s * 3 + 1] - py;
-                        const double dz = sorted_xyz[(i64)s * 3 + 2] - pz;
+                        const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)s * kRec);
+                        const double2 xy = r2[0], zw = r2[1];
+                        const double dx = xy.x - px;
+                        const double dy = xy.y - py;
+                        const double dz = zw.x - pz;
                         double d2 = dx * dx;
                         d2 = d2 + dy * dy;
                         if (ndim > 2) d2 = d2 + dz * dz;
-                        const int sid = sorted_id[s];
+                        const int sid = record_id(zw.y);
                         if (before(d2, sid, best.d[K - 1], best.id[K - 1])) best.insert(d2, sid);
                     }
                 }
@@ -377,7 +390,6 @@ template <int K>
 __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsrc,
                                                            const int *__restrict__ cell_start,
                                                            const double *__restrict__ sorted_xyz,
-                                                           const int *__restrict__ sorted_id,
                                                            const double *__restrict__ pts, i64 npts, int ndim,
                                                            int kout, i64 *__restrict__ idx_out,
                                                            double *__restrict__ dist_out,
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
     const i64 total = list ? (i64)*list_count : npts;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
-        knn_query_one<K>(g, nsrc, cell_start, sorted_xyz, sorted_id, pts, ndim, kout, idx_out, dist_out,
+        knn_query_one<K>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
                          list ? (i64)list[q] : q);
 }
 
@@ -456,10 +468,8 @@ template <int K, int CAP>
 __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 nsrc,
                                                             const int *__restrict__ cell_start,
                                                             const double *__restrict__ sorted_xyz,
-                                                            const int *__restrict__ sorted_id,
-                                                            const double *__restrict__ pts, int ndim, int kout,
+                                                             const double *__restrict__ pts, int ndim, int kout,
                                                             const int *__restrict__ tstart,
-                                                            const int *__restrict__ perm,
                                                             const double *__restrict__ tsorted,
                                                             i64 *__restrict__ idx_out,
                                                             double *__restrict__ dist_out,
@@ -549,7 +559,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
     if (dbg_stop == 7) { if (total == 12345 && scale == 1.f) fb_list[0] = 1; return; }
     if (!cell_ok) {
         // the whole cell goes to the generic kernel
-        for (int q = lane; q < tn; q += kWave) fb_list[atomicAdd(fb_count, 1)] = perm[t0 + q];
+        for (int q = lane; q < tn; q += kWave)
+            fb_list[atomicAdd(fb_count, 1)] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
         return;
     }
 
@@ -566,13 +577,15 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
 
     // first round's targets: cell-sorted copies of the coordinates (contiguous, no indirection);
     // issued before the tile loads so that both are in flight together
-    double npx, npy, npz;
+    double npx, npy, npz, npw;
     {
         const bool v = tg < tn;
-        const i64 q = (i64)(t0 + (v ? tg : 0)) * 3;
-        npx = tsorted[q + 0];
-        npy = tsorted[q + 1];
-        npz = tsorted[q + 2];
+        const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (v ? tg : 0)) * kRec);
+        const double2 xy = r2[0], zw = r2[1];
+        npx = xy.x;
+        npy = xy.y;
+        npz = zw.x;
+        npw = zw.y;
     }
 
     // ---- stage the tile: every run holds at most 64 sources, so lane l fetches source l of each
@@ -585,9 +598,11 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const i64 s = (i64)rs[c3 + c] + min(lane, max(rl[c3 + c] - 1, 0));
-                sx[c] = sorted_xyz[s * 3 + 0];
-                sy[c] = sorted_xyz[s * 3 + 1];
-                sz[c] = sorted_xyz[s * 3 + 2];
+                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
+                const double2 xy = r2[0];
+                sx[c] = xy.x;
+                sy[c] = xy.y;
+                sz[c] = r2[1].x;
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -604,17 +619,19 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
     for (int r0 = 0; r0 < tn; r0 += tpw) {
         const int tt = r0 + tg;
         const bool valid = tt < tn;
-        const i64 i = valid ? (i64)perm[t0 + tt] : 0;  // only needed for the output row
+        const i64 i = valid ? (i64)record_id(npw) : 0;  // the target's original index
         const double px = valid ? npx : ox;
         const double py = valid ? npy : oy;
         const double pz = valid ? npz : oz;
         if (r0 + tpw < tn) {
             // next round's targets, in flight during this round
             const bool v = tt + tpw < tn;
-            const i64 q = (i64)(t0 + (v ? tt + tpw : 0)) * 3;
-            npx = tsorted[q + 0];
-            npy = tsorted[q + 1];
-            npz = tsorted[q + 2];
+            const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (v ? tt + tpw : 0)) * kRec);
+            const double2 xy = r2[0], zw = r2[1];
+            npx = xy.x;
+            npy = xy.y;
+            npz = zw.x;
+            npw = zw.y;
         }
         const float tx = (float)(px - ox), ty = (float)(py - oy), tz = (float)(pz - oz);
         const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy + g.hz));
@@ -726,14 +743,16 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
             rank[o] = 0;
             if (live) {
                 const i64 s = (i64)s_bx[e][tg];
-                const double dx = sorted_xyz[s * 3 + 0] - px;
-                const double dy = sorted_xyz[s * 3 + 1] - py;
-                const double dz = sorted_xyz[s * 3 + 2] - pz;
+                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
+                const double2 xy = r2[0], zw = r2[1];
+                const double dx = xy.x - px;
+                const double dy = xy.y - py;
+                const double dz = zw.x - pz;
                 double d2 = dx * dx;
                 d2 = d2 + dy * dy;
                 if (ndim > 2) d2 = d2 + dz * dz;
                 ed[o] = d2;
-                ei[o] = sorted_id[s];
+                ei[o] = record_id(zw.y);
                 s_bd[e][tg] = d2;
                 s_bx[e][tg] = ei[o];
             }
@@ -829,18 +848,17 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
 }
 
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
-__global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int *__restrict__ cell_of, i64 npts,
+__global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__restrict__ cell_of, i64 npts,
                                                                 const double *__restrict__ pts, int ndim,
-                                                                int *__restrict__ cursor, int *__restrict__ perm,
+                                                                const int *__restrict__ start,
                                                                 double *__restrict__ tsorted)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npts) return;
-    const int pos = atomicAdd(&cursor[cell_of[t]], 1);
-    perm[pos] = (int)t;
-    tsorted[(i64)pos * 3 + 0] = pts[t * ndim];
-    tsorted[(i64)pos * 3 + 1] = ndim > 1 ? pts[t * ndim + 1] : 0.0;
-    tsorted[(i64)pos * 3 + 2] = ndim > 2 ? pts[t * ndim + 2] : 0.0;
+    const int2 cr = cell_of[t];
+    const i64 pos = (i64)start[cr.x] + cr.y;
+    store_record(tsorted + pos * kRec, pts[t * ndim], ndim > 1 ? pts[t * ndim + 1] : 0.0,
+                 ndim > 2 ? pts[t * ndim + 2] : 0.0, (int)t);
 }
 
 template <int K>
@@ -850,13 +868,13 @@ void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g
     i64 grid = (npts + kBlock - 1) / kBlock;
     if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
     hipLaunchKernelGGL((knn_query_kernel<K>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
-                       ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, npts, ix->ndim, kout, idx, dist, list,
+                       ix->cell_start, ix->sorted_xyz, pts, npts, ix->ndim, kout, idx, dist, list,
                        list_count);
 }
 
 template <int K>
 void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                 int kout, const int *tstart, const int *perm, const double *tsorted, i64 *idx, double *dist,
+                 int kout, const int *tstart, const double *tsorted, i64 *idx, double *dist,
                  int *fb_list, int *fb_count)
 {
     constexpr int CAP = K + 12;
@@ -866,8 +884,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     const i64 cell_grid = 8 * ((cols + 7) / 8) * ix->dims[2];
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
-                       ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->sorted_id, pts, ix->ndim, kout, tstart, perm,
-                       tsorted, idx, dist, fb_list, fb_count, dbg_stop);
+                       ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
     mm_stage_end(ctx, MM_STAGE_KNN_CELL);
     launch_generic<K>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
@@ -896,7 +913,6 @@ void free_index(mm_knn_index *ix)
     if (!ix->borrowed) {
         if (ix->cell_start) (void)hipFree(ix->cell_start);
         if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
-        if (ix->sorted_id) (void)hipFree(ix->sorted_id);
     }
     delete ix;
 }
@@ -976,11 +992,8 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         ix->borrowed = true;
         int brc = mm_buffer_get(ctx, MM_BUF_CELL_START, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
         if (brc == MM_OK)
-            brc = mm_buffer_get(ctx, MM_BUF_SORTED_XYZ, (size_t)(nsrc > 0 ? nsrc : 1) * 3 * sizeof(double),
+            brc = mm_buffer_get(ctx, MM_BUF_SORTED_XYZ, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double),
                                 (void **)&ix->sorted_xyz);
-        if (brc == MM_OK)
-            brc = mm_buffer_get(ctx, MM_BUF_SORTED_ID, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int),
-                                (void **)&ix->sorted_id);
         if (brc != MM_OK) {
             free_index(ix);
             return brc;
@@ -988,8 +1001,7 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     } else {
         e = hipMalloc((void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
         if (e == hipSuccess)
-            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * 3 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&ix->sorted_id, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
+            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double));
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_ALLOC, "kNN index allocation failed: %s", hipGetErrorString(e));
             free_index(ix);
@@ -997,16 +1009,15 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         }
     }
     const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
-    size_t need = mm_round256((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int)) +     // cell_of
-                  2 * mm_round256((size_t)(ncells + 1) * sizeof(int)) +          // counts, cursor
+    size_t need = mm_round256((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int2)) +    // cell_of {cell, rank}
+                  mm_round256((size_t)(ncells + 1) * sizeof(int)) +              // counts
                   mm_round256((size_t)ntiles * sizeof(int)) + 4096;
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) { free_index(ix); return rc; }
-    int *cell_of = (int *)mm_scratch_take(ctx, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
+    int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int2));
     int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
-    int *cursor = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
     int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
-    if (!cell_of || !counts || !cursor || !tile_sums) {
+    if (!cell_of || !counts || !tile_sums) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         free_index(ix);
         return MM_ERR_ALLOC;
@@ -1020,10 +1031,10 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
-                       ix->cell_start, cursor);
+                       ix->cell_start);
     if (nsrc > 0)
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim,
-                           cell_of, cursor, ix->sorted_xyz, ix->sorted_id);
+                           cell_of, ix->cell_start, ix->sorted_xyz);
     e = hipGetLastError();
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "kNN build launch: %s", hipGetErrorString(e));
@@ -1051,22 +1062,21 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
     // scratch: visiting order of the targets (counting sort by cell) + straggler queue
     const i64 ncells = ix->ncells;
     const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
-    const size_t need = 3 * mm_round256((size_t)npts * sizeof(int)) +           // cell_of, perm, fb_list
-                        mm_round256((size_t)npts * 3 * sizeof(double)) +        // cell-sorted target coordinates
-                        3 * mm_round256((size_t)(ncells + 1) * sizeof(int)) +   // counts, start, cursor
+    const size_t need = mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
+                        mm_round256((size_t)npts * sizeof(int)) +               // fb_list
+                        mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
+                        2 * mm_round256((size_t)(ncells + 1) * sizeof(int)) +   // counts, start
                         mm_round256((size_t)ntiles * sizeof(int)) + 1024;
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) return rc;
-    int *cell_of = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
-    int *perm = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
     int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
     int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
     int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
-    int *cursor = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
     int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
     int *fb_count = (int *)mm_scratch_take(ctx, 256);
-    double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * 3 * sizeof(double));
-    if (!tsorted || !cell_of || !perm || !fb_list || !counts || !start || !cursor || !tile_sums || !fb_count) {
+    double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
+    if (!tsorted || !cell_of || !fb_list || !counts || !start || !tile_sums || !fb_count) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
@@ -1077,19 +1087,18 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
                        counts);
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start,
-                       cursor);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
     hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, ix->ndim,
-                       cursor, perm, tsorted);
+                       start, tsorted);
 
-    if (k <= 1) launch_fast<1>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 2) launch_fast<2>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 4) launch_fast<4>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 8) launch_fast<8>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 16) launch_fast<16>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 20) launch_fast<20>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 25) launch_fast<25>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else launch_fast<32>(ctx, ix, g, pts_d, npts, kout, start, perm, tsorted, idx_d, dist_d, fb_list, fb_count);
+    if (k <= 1) launch_fast<1>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 2) launch_fast<2>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 4) launch_fast<4>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 8) launch_fast<8>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 16) launch_fast<16>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 20) launch_fast<20>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 25) launch_fast<25>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else launch_fast<32>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
     MM_HIP_CHECK(hipGetLastError());
     if (getenv("MM_KNN_DEBUG")) {
         int h = 0;
