@@ -919,6 +919,18 @@ void free_index(mm_knn_index *ix)
 
 }  // namespace
 
+// Exclusive prefix sum of n ints on the context's stream: start[0..n] (start[n] = total).
+// tile_sums: scratch of ceil(n / 1024) ints.  Shared with the GLL locate's target ordering.
+int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums)
+{
+    const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums);
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums, start);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
 // Build without touching the stage timers (used by the fused pipeline too).
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
                       bool use_context_buffers)

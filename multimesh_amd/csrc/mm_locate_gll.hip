@@ -15,8 +15,11 @@
 // component is < 1e-12, at most 25 updates; NaN when an iterate leaves [-10,10] or the iteration
 // does not converge.  Same operation order as the oracle, no fused multiply-add.
 //
-// One lane per target, control nodes streamed from L2 each Newton step (first version: correct
-// and complete; the element-centric LDS-tiled variant is future work).
+// One lane per target, control nodes streamed from L1/L2 each Newton step.  Targets are visited in
+// the order of their FIRST candidate element (a counting sort by nn[:,0] on the device), so the
+// lanes of a wave mostly work on the same element and their control-node loads collapse to one
+// cache line per instruction instead of up to 64.  (An element-centric LDS-tiled variant is the
+// next step, see DESIGN.md.)
 #include <math.h>
 
 #include "mm_common.h"
@@ -34,7 +37,7 @@ __device__ __forceinline__ void gll_nodes(double (&g)[ORDER + 1])
         g[1] = 0.0;
         g[ORDER] = 1.0;
     } else {
-        const double a = sqrt(3.0 / 7.0);
+        const double a = 0x1.4f2ec413cb52ap-1;  // sqrt(3/7)
         g[0] = -1.0;
         g[1] = -a;
         g[ORDER / 2] = 0.0;
@@ -43,27 +46,39 @@ __device__ __forceinline__ void gll_nodes(double (&g)[ORDER + 1])
     }
 }
 
-// 1-D Lagrange values and derivatives, product formulas in a fixed loop order (== oracle)
+// 1-D Lagrange values and derivatives: product formulas in a fixed loop order with precomputed
+// reciprocals of the node differences (compile-time constants here), identical to the oracle:
+//   e[i][m] = (x - g[m]) * (1 / (g[i] - g[m]));  l[i] = prod_{m != i} e[i][m];
+//   dl[i] = sum_{m != i} (1/(g[i]-g[m])) * prod_{q != i,m} e[i][q]
 template <int ORDER>
 __device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double x, double (&l)[ORDER + 1],
                                             double (&dl)[ORDER + 1])
 {
     constexpr int n = ORDER + 1;
+    double inv[n][n], e[n][n];
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int m = 0; m < n; ++m)
+            if (m != i) {
+                inv[i][m] = 1.0 / (g[i] - g[m]);
+                e[i][m] = (x - g[m]) * inv[i][m];
+            }
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         double v = 1.0;
 #pragma unroll
         for (int m = 0; m < n; ++m)
-            if (m != i) v = v * ((x - g[m]) / (g[i] - g[m]));
+            if (m != i) v = v * e[i][m];
         l[i] = v;
         double d = 0.0;
 #pragma unroll
         for (int m = 0; m < n; ++m) {
             if (m == i) continue;
-            double t = 1.0 / (g[i] - g[m]);
+            double t = inv[i][m];
 #pragma unroll
             for (int q = 0; q < n; ++q)
-                if (q != i && q != m) t = t * ((x - g[q]) / (g[i] - g[q]));
+                if (q != i && q != m) t = t * e[i][q];
             d = d + t;
         }
         dl[i] = d;
@@ -99,7 +114,10 @@ struct Gll {
 #pragma unroll
                 for (int k = 0; k < n; ++k)
 #pragma unroll
-                    for (int j = 0; j < n; ++j)
+                    for (int j = 0; j < n; ++j) {
+                        // keep the scheduler from hoisting all (order+1)^3 node loads to the top of
+                        // the unrolled loop (256 VGPRs, one wave per SIMD): one row of nodes at a time
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < n; ++i) {
                             const double *X = ctrl + 3 * (i + n * (j + n * k));
@@ -116,6 +134,7 @@ struct Gll {
                                 J[a][DIM - 1] = J[a][DIM - 1] + g2 * Xa;
                             }
                         }
+                    }
             } else {
 #pragma unroll
                 for (int j = 0; j < n; ++j)
@@ -206,13 +225,15 @@ __global__ __launch_bounds__(64) void locate_gll_kernel(i64 k, i64 npoints, cons
                                                         const double *__restrict__ points, double tolerance,
                                                         int snap_to_nearest, i64 *__restrict__ elem,
                                                         double *__restrict__ coeffs,
-                                                        unsigned long long *__restrict__ nmissing)
+                                                        unsigned long long *__restrict__ nmissing,
+                                                        const int *__restrict__ order)
 {
     using G = Gll<ORDER, DIM>;
     constexpr int P = G::P;
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     bool missing = false;
-    if (i < npoints) {
+    if (t < npoints) {
+        const i64 i = order ? (i64)order[t] : t;
         double pnt[DIM];
 #pragma unroll
         for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
@@ -328,14 +349,37 @@ __global__ __launch_bounds__(256) void gather_elem_kernel(const double *__restri
 
 template <int ORDER, int DIM>
 void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const double *gll, i64 nelem,
-                   const double *pts, double tol, int snap, i64 *elem, double *coeffs, unsigned long long *nmiss)
+                   const double *pts, double tol, int snap, i64 *elem, double *coeffs, unsigned long long *nmiss,
+                   const int *order)
 {
     const i64 grid = (npoints + 63) / 64;
     hipLaunchKernelGGL((locate_gll_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k, npoints, nn,
-                       gll, nelem, pts, tol, snap, elem, coeffs, nmiss);
+                       gll, nelem, pts, tol, snap, elem, coeffs, nmiss, order);
+}
+
+// visiting order: counting sort of the targets by their first candidate element
+__global__ __launch_bounds__(256) void gll_key_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn, i64 nelem,
+                                                      int2 *__restrict__ key_rank, int *__restrict__ counts)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npoints) return;
+    const i64 e = nn[t * k];
+    const int key = (unsigned long long)e < (unsigned long long)nelem ? (int)e : (int)nelem;  // invalid -> last bin
+    key_rank[t] = make_int2(key, atomicAdd(&counts[key], 1));
+}
+
+__global__ __launch_bounds__(256) void gll_order_kernel(i64 npoints, const int2 *__restrict__ key_rank,
+                                                        const int *__restrict__ start, int *__restrict__ order)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npoints) return;
+    const int2 kr = key_rank[t];
+    order[start[kr.x] + kr.y] = (int)t;
 }
 
 }  // namespace
+
+int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums);
 
 extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k, int64_t npoints,
                                  const int64_t *nn_d, const double *gll_points_d, int64_t nelem,
@@ -352,15 +396,41 @@ extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k,
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(i64), ctx->stream));
+    MM_REQUIRE(npoints < (int64_t)0x7fffffff && nelem < (int64_t)0x7ffffff0, "too many targets / elements");
     if (npoints > 0) {
         mm_stage_begin(ctx, MM_STAGE_LOCATE);
         unsigned long long *nm = (unsigned long long *)ctx->d_counters;
+        // visiting order (skipped when there are no candidates)
+        const int *visit = nullptr;
+        if (k > 0 && nelem > 0) {
+            const i64 nbins = nelem + 1;
+            const i64 ntiles = (nbins + 1023) / 1024;
+            int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int2)) +
+                                               mm_round256((size_t)npoints * sizeof(int)) +
+                                               2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
+                                               mm_round256((size_t)ntiles * sizeof(int)) + 1024);
+            if (rc != MM_OK) return rc;
+            int2 *key_rank = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+            int *ord = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
+            int *counts = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+            int *start = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+            int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
+            MM_REQUIRE(key_rank && ord && counts && start && tile_sums, "scratch carve failed");
+            MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(nbins + 1) * sizeof(int), ctx->stream));
+            const unsigned gp = (unsigned)((npoints + 255) / 256);
+            hipLaunchKernelGGL(gll_key_kernel, dim3(gp), dim3(256), 0, ctx->stream, k, npoints, (const i64 *)nn_d, nelem,
+                               key_rank, counts);
+            rc = mm_exclusive_scan_int(ctx, counts, nbins, start, tile_sums);
+            if (rc != MM_OK) return rc;
+            hipLaunchKernelGGL(gll_order_kernel, dim3(gp), dim3(256), 0, ctx->stream, npoints, key_rank, start, ord);
+            visit = ord;
+        }
         const i64 *nn = (const i64 *)nn_d;
         i64 *el = (i64 *)elem_d;
 #define MM_GLL_CASE(O, D)                                                                                      \
     if (order == O && dim == D)                                                                                \
         launch_locate<O, D>(ctx, k, npoints, nn, gll_points_d, nelem, points_d, tolerance, snap_to_nearest, el, \
-                            coeffs_d, nm);
+                            coeffs_d, nm, visit);
         MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
 #undef MM_GLL_CASE
         mm_stage_end(ctx, MM_STAGE_LOCATE);

@@ -387,25 +387,36 @@ static void gll_nodes(int order, double *g)
 {
     if (order == 1) { g[0] = -1.0; g[1] = 1.0; }
     else if (order == 2) { g[0] = -1.0; g[1] = 0.0; g[2] = 1.0; }
-    else { const double a = sqrt(3.0 / 7.0); g[0] = -1.0; g[1] = -a; g[2] = 0.0; g[3] = a; g[4] = 1.0; }
+    else { const double a = 0x1.4f2ec413cb52ap-1; /* sqrt(3/7) */ g[0] = -1.0; g[1] = -a; g[2] = 0.0; g[3] = a; g[4] = 1.0; }
 }
 
-/* 1-D Lagrange values l[i] and derivatives dl[i] at x, straightforward product formulas with a
- * fixed loop order (the HIP kernel uses the same). */
+/* 1-D Lagrange values l[i] and derivatives dl[i] at x.  Product formulas with a fixed loop order
+ * and PRECOMPUTED reciprocals of the node differences (no divisions in the hot loop); the HIP
+ * kernel does exactly the same operations:
+ *   e[i][m] = (x - g[m]) * (1 / (g[i] - g[m]))
+ *   l[i]    = prod_{m != i} e[i][m]                      (m ascending, starting from 1.0)
+ *   dl[i]   = sum_{m != i} (1/(g[i]-g[m])) * prod_{q != i,m} e[i][q] */
 static void lagrange_1d(int order, const double *g, double x, double *l, double *dl)
 {
     const int n = order + 1;
+    double inv[5][5], e[5][5];
+    for (int i = 0; i < n; ++i)
+        for (int m = 0; m < n; ++m)
+            if (m != i) {
+                inv[i][m] = 1.0 / (g[i] - g[m]);
+                e[i][m] = (x - g[m]) * inv[i][m];
+            }
     for (int i = 0; i < n; ++i) {
         double v = 1.0;
         for (int m = 0; m < n; ++m)
-            if (m != i) v = v * ((x - g[m]) / (g[i] - g[m]));
+            if (m != i) v = v * e[i][m];
         l[i] = v;
         double d = 0.0;
         for (int m = 0; m < n; ++m) {
             if (m == i) continue;
-            double t = 1.0 / (g[i] - g[m]);
+            double t = inv[i][m];
             for (int q = 0; q < n; ++q)
-                if (q != i && q != m) t = t * ((x - g[q]) / (g[i] - g[q]));
+                if (q != i && q != m) t = t * e[i][q];
             d = d + t;
         }
         dl[i] = d;
