@@ -136,7 +136,9 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MM_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) even at world size 1
+    use_dist = world > 1 or (os.environ.get("MM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -159,7 +161,7 @@ def main():
     t_fields = torch.from_numpy(fields).to(dev)
     n_local = pb.shape[0]
     t_out = torch.empty((n_local, ncomp), dtype=torch.float64, device=dev)
-    t_all = torch.empty((world * n_local, ncomp), dtype=torch.float64, device=dev) if world > 1 else None
+    t_all = torch.empty((world * n_local, ncomp), dtype=torch.float64, device=dev) if use_dist else None
 
     from multimesh_amd.device import Context
 
@@ -173,7 +175,7 @@ def main():
     def step(record):
         nonlocal nfailed_total
         _, nf = ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, out=t_out)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(t_all, t_out)
         if record:
             nfailed_total += nf
@@ -183,17 +185,17 @@ def main():
     for _ in range(args.warmup):
         step(False)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -253,8 +255,11 @@ def main():
             line["parity_vs_cpu_sample"] = bool(np.array_equal(got, vals_c))
         print(json.dumps(line), flush=True)
 
+    if use_dist and rank == 0 and t_all is not None:
+        # the gathered field must hold every rank's block; rank 0's own block is checked here
+        assert torch.equal(t_all[:n_local], t_out), "all-gather did not return this rank's block"
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

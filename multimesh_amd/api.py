@@ -61,6 +61,49 @@ def apply_operator(mesh_a: HexMesh, enclosing_elem_node_indices, weights, params
     return ctx.gather(mesh_a.fields_matrix(params), enclosing_elem_node_indices, weights).numpy()
 
 
+def load_stored_operator(stored_array):
+    """The reference's operator cache (interpolator.py:724-740): ``elements.npy`` + ``coeffs.npy`` in
+    the ``stored_array`` directory.  Returns ``(elements, coeffs)`` or ``None`` when not (fully) there.
+    For the hex8 path ``elements`` holds the 8 node ids per point (``enclosing_elem_node_indices``)."""
+    import os
+
+    if not stored_array:
+        return None
+    e_path, c_path = os.path.join(stored_array, "elements.npy"), os.path.join(stored_array, "coeffs.npy")
+    if not (os.path.exists(e_path) and os.path.exists(c_path)):
+        return None
+    coeffs = np.load(c_path, allow_pickle=True)
+    elements = np.load(e_path, allow_pickle=True)
+    assert not np.isnan(coeffs).any(), "Stored coeffs matrix has NaNs"          # interpolator.py:735-740
+    return elements, coeffs
+
+
+def save_stored_operator(stored_array, elements, coeffs):
+    """reference interpolator.py:797-810"""
+    import os
+
+    if not os.path.exists(stored_array):
+        os.makedirs(stored_array)
+    print("Will save matrices for later usage")
+    np.save(os.path.join(stored_array, "elements.npy"), elements, allow_pickle=True)
+    np.save(os.path.join(stored_array, "coeffs.npy"), coeffs, allow_pickle=True)
+
+
+def interpolate_cached(mesh_a: HexMesh, points, params, stored_array=None, nelem_to_search=20, context=None):
+    """hex8 interpolation with the reference's ``stored_array`` split: the first
+    call builds and stores the operator, later calls skip kNN + locate and run only the HBM-bound
+    gather.  Returns f64[N, len(params)]."""
+    cached = load_stored_operator(stored_array)
+    if cached is None:
+        enc, w, _ = interpolate_operator(mesh_a, points, nelem_to_search, context)
+        if stored_array:
+            save_stored_operator(stored_array, enc, w)
+    else:
+        print("Matrix was already stored. Will use that one")
+        enc, w = cached
+    return apply_operator(mesh_a, enc, w, params, context)
+
+
 def interpolate_mesh_a_to_b(mesh_a: HexMesh, mesh_b: HexMesh, params=("TTI",), context=None):
     """Interpolates values from mesh A onto the nodes of mesh B (reference cli.py:41-104).
 

@@ -56,6 +56,19 @@ def test_interpolate_to_points_and_operator_split():
         api.gll_2_gll("a.h5", "b.h5")
 
 
+def test_stored_operator_cache_round_trip(tmp_path):
+    from multimesh_amd import api
+
+    a, b = _meshes()
+    first = api.interpolate_cached(a, b.points, ["VSV", "RHO"], stored_array=str(tmp_path / "op"))
+    assert (tmp_path / "op" / "coeffs.npy").exists() and (tmp_path / "op" / "elements.npy").exists()
+    a.attach_field("VSV", 2.0 * a.get_nodal_field("VSV"))                         # a new model iteration
+    second = api.interpolate_cached(a, b.points, ["VSV", "RHO"], stored_array=str(tmp_path / "op"))
+    assert np.array_equal(second[:, 1], first[:, 1]) and np.array_equal(second[:, 0], 2.0 * first[:, 0])
+    truth, _, _, _ = _oracle_values(a, b.points, ["VSV", "RHO"], 20)
+    assert np.array_equal(second, truth)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
