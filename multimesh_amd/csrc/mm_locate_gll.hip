@@ -218,80 +218,145 @@ struct Gll {
     }
 };
 
-// control flow of reference interpolator.py:1181-1233 (see the oracle's mmo_locate_gll)
+// Control flow of reference interpolator.py:1181-1233 (see the oracle's mmo_locate_gll), scheduled
+// as COMPACTING PASSES like the hex8 locate: a pass performs at most one inverse transform per
+// still-open target (candidate j of its list) and re-queues the unresolved ones densely as (target,
+// j+1), so a wave never waits for its unluckiest lane's whole candidate walk.  k passes are launched
+// (each advances every open target by at least one candidate), the late ones over a nearly empty
+// queue.  With snap_to_nearest the least-outside candidate seen so far travels in per-target state
+// arrays.  Re-queue entries are batched per wave in LDS (one global atomic per ~200 entries).
+constexpr int kGllWaveQueue = 256;
+
 template <int ORDER, int DIM>
-__global__ __launch_bounds__(64) void locate_gll_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
-                                                        const double *__restrict__ gll_points, i64 nelem,
-                                                        const double *__restrict__ points, double tolerance,
-                                                        int snap_to_nearest, i64 *__restrict__ elem,
-                                                        double *__restrict__ coeffs,
-                                                        unsigned long long *__restrict__ nmissing,
-                                                        const int *__restrict__ order)
+__global__ __launch_bounds__(64) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+                                                             const double *__restrict__ gll_points, i64 nelem,
+                                                             const double *__restrict__ points, double tolerance,
+                                                             int snap_to_nearest, i64 *__restrict__ elem,
+                                                             double *__restrict__ coeffs,
+                                                             unsigned long long *__restrict__ nmissing,
+                                                             const int *__restrict__ order,
+                                                             const int2 *__restrict__ q_in,
+                                                             const int *__restrict__ q_in_count,
+                                                             int2 *__restrict__ q_out, int *__restrict__ q_out_count,
+                                                             double *__restrict__ best_state,   // [N][DIM+1]
+                                                             i64 *__restrict__ best_elem_state)  // [N]
 {
     using G = Gll<ORDER, DIM>;
     constexpr int P = G::P;
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    bool missing = false;
-    if (t < npoints) {
-        const i64 i = order ? (i64)order[t] : t;
-        double pnt[DIM];
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
-        double best_xi[DIM];
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) best_xi[d] = 10e9;
-        double best_val = 10e9;
-        i64 best_elem = 0;
-        bool found = false;
-        double xi[DIM];
-        for (i64 j = 0; j < k && !found; ++j) {
-            const i64 e = nn[i * k + j];
-            if (e < 0 || e >= nelem) continue;
-            G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
-            bool isnan_any = false;
-            double worst = 0.0;
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) {
-                if (xi[d] != xi[d]) isnan_any = true;
-                if (fabs(xi[d]) > worst) worst = fabs(xi[d]);
+    __shared__ int2 s_queue[kGllWaveQueue];
+    const int lane = threadIdx.x;
+    int held = 0;
+    unsigned long long missing_total = 0;
+
+    const i64 total = q_in ? (i64)*q_in_count : npoints;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 trips = (total + stride - 1) / stride;
+    for (i64 trip = 0; trip < trips; ++trip) {
+        const i64 q = first + trip * stride;
+        const bool active = q < total;
+        bool requeue = false, missing = false;
+        i64 i = 0;
+        int j = 0;
+        if (active) {
+            if (q_in) {
+                const int2 e = q_in[q];
+                i = e.x;
+                j = e.y;
+            } else {
+                i = order ? (i64)order[q] : q;
             }
-            if (isnan_any) continue;
-            if (worst < best_val) {
-                best_val = worst;
-                best_elem = e;
+            double pnt[DIM];
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) best_xi[d] = xi[d];
-            }
-            bool inside = true;
+            for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
+            // least-outside candidate so far (fresh in the first pass)
+            double best_xi[DIM];
+            double best_val = 10e9;
+            i64 best_elem = 0;
 #pragma unroll
-            for (int d = 0; d < DIM; ++d)
-                if (!(fabs(xi[d]) < tolerance)) inside = false;
-            if (inside) {
-                elem[i] = e;
-                G::coefficients(xi, coeffs + i * P);
-                found = true;
+            for (int d = 0; d < DIM; ++d) best_xi[d] = 10e9;
+            if (snap_to_nearest && q_in) {
+                best_val = best_state[i * (DIM + 1)];
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) best_xi[d] = best_state[i * (DIM + 1) + 1 + d];
+                best_elem = best_elem_state[i];
             }
-        }
-        if (!found) {
-            if (snap_to_nearest) {
+            // next valid candidate
+            while (j < k) {
+                const i64 e = nn[i * k + j];
+                if (e >= 0 && e < nelem) break;
+                ++j;
+            }
+            bool found = false;
+            if (j < k) {
+                const i64 e = nn[i * k + j];
+                double xi[DIM];
+                G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
+                bool isnan_any = false;
+                double worst = 0.0;
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) {
-                    double v = best_xi[d];
-                    if (v < -1.02) v = -1.02;
-                    if (v > 1.02) v = 1.02;
-                    best_xi[d] = v;
+                    if (xi[d] != xi[d]) isnan_any = true;
+                    if (fabs(xi[d]) > worst) worst = fabs(xi[d]);
                 }
-                elem[i] = best_elem;
-                G::coefficients(best_xi, coeffs + i * P);
-            } else {
-                elem[i] = -1;
-                for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
-                missing = true;
+                if (!isnan_any) {
+                    if (worst < best_val) {
+                        best_val = worst;
+                        best_elem = e;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) best_xi[d] = xi[d];
+                    }
+                    bool inside = true;
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d)
+                        if (!(fabs(xi[d]) < tolerance)) inside = false;
+                    if (inside) {
+                        elem[i] = e;
+                        G::coefficients(xi, coeffs + i * P);
+                        found = true;
+                    }
+                }
+                ++j;
+            }
+            if (!found) {
+                if (j < k) {
+                    requeue = true;
+                    if (snap_to_nearest) {
+                        best_state[i * (DIM + 1)] = best_val;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) best_state[i * (DIM + 1) + 1 + d] = best_xi[d];
+                        best_elem_state[i] = best_elem;
+                    }
+                } else if (snap_to_nearest) {
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) {
+                        double v = best_xi[d];
+                        if (v < -1.02) v = -1.02;
+                        if (v > 1.02) v = 1.02;
+                        best_xi[d] = v;
+                    }
+                    elem[i] = best_elem;
+                    G::coefficients(best_xi, coeffs + i * P);
+                } else {
+                    elem[i] = -1;
+                    for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                    missing = true;
+                }
             }
         }
+        missing_total += __popcll(__ballot(missing));
+        const unsigned long long vote = __ballot(requeue);
+        if (requeue) s_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
+        held += __popcll(vote);
+        if (held > kGllWaveQueue - 64 || (trip == trips - 1 && held > 0)) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(q_out_count, held);
+            base = __shfl(base, 0);
+            for (int t = lane; t < held; t += 64) q_out[base + t] = s_queue[t];
+            held = 0;
+        }
     }
-    const unsigned long long mask = __ballot(missing);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nmissing, (unsigned long long)__popcll(mask));
+    if (lane == 0 && missing_total) atomicAdd(nmissing, missing_total);
 }
 
 template <int CTRL>
@@ -350,11 +415,21 @@ __global__ __launch_bounds__(256) void gather_elem_kernel(const double *__restri
 template <int ORDER, int DIM>
 void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const double *gll, i64 nelem,
                    const double *pts, double tol, int snap, i64 *elem, double *coeffs, unsigned long long *nmiss,
-                   const int *order)
+                   const int *order, int2 *qa, int2 *qb, int *counters, double *best_state, i64 *best_elem_state)
 {
-    const i64 grid = (npoints + 63) / 64;
-    hipLaunchKernelGGL((locate_gll_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k, npoints, nn,
-                       gll, nelem, pts, tol, snap, elem, coeffs, nmiss, order);
+    const i64 full_grid = (npoints + 63) / 64;
+    const i64 npasses = k > 0 ? k : 1;
+    for (i64 p = 0; p < npasses; ++p) {
+        const int2 *q_in = p == 0 ? nullptr : ((p & 1) ? qa : qb);
+        int2 *q_out = (p & 1) ? qb : qa;
+        // persistent waves; later passes only know their size on the device
+        i64 grid = full_grid >> (p < 6 ? p : 6);
+        if (grid > 16384) grid = 16384;
+        if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
+        hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k,
+                           npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, p == 0 ? order : nullptr, q_in,
+                           p == 0 ? nullptr : counters + p, q_out, counters + p + 1, best_state, best_elem_state);
+    }
 }
 
 // visiting order: counting sort of the targets by their first candidate element
@@ -400,16 +475,26 @@ extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k,
     if (npoints > 0) {
         mm_stage_begin(ctx, MM_STAGE_LOCATE);
         unsigned long long *nm = (unsigned long long *)ctx->d_counters;
-        // visiting order (skipped when there are no candidates)
+        // scratch: visiting order, two pass queues, their counters, snap state
         const int *visit = nullptr;
+        const i64 nbins = nelem + 1;
+        const i64 ntiles = (nbins + 1023) / 1024;
+        int rc = mm_scratch_begin(ctx, 3 * mm_round256((size_t)npoints * sizeof(int2)) +
+                                           mm_round256((size_t)npoints * sizeof(int)) +
+                                           2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
+                                           mm_round256((size_t)ntiles * sizeof(int)) +
+                                           (snap_to_nearest ? mm_round256((size_t)npoints * 5 * sizeof(double)) : 0) +
+                                           mm_round256(sizeof(int) * (MM_KNN_MAX_K + 8)) + 4096);
+        if (rc != MM_OK) return rc;
+        int2 *qa = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+        int2 *qb = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+        int *counters = (int *)mm_scratch_take(ctx, sizeof(int) * (MM_KNN_MAX_K + 8));
+        double *best_state = snap_to_nearest ? (double *)mm_scratch_take(ctx, (size_t)npoints * 4 * sizeof(double)) : nullptr;
+        i64 *best_elem_state = snap_to_nearest ? (i64 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(i64)) : nullptr;
+        MM_REQUIRE(qa && qb && counters && (!snap_to_nearest || (best_state && best_elem_state)), "scratch carve failed");
+        MM_REQUIRE(k <= MM_KNN_MAX_K, "nelem_to_search must be <= MM_KNN_MAX_K");
+        MM_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int) * (MM_KNN_MAX_K + 8), ctx->stream));
         if (k > 0 && nelem > 0) {
-            const i64 nbins = nelem + 1;
-            const i64 ntiles = (nbins + 1023) / 1024;
-            int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int2)) +
-                                               mm_round256((size_t)npoints * sizeof(int)) +
-                                               2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
-                                               mm_round256((size_t)ntiles * sizeof(int)) + 1024);
-            if (rc != MM_OK) return rc;
             int2 *key_rank = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
             int *ord = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
             int *counts = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
@@ -430,7 +515,7 @@ extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k,
 #define MM_GLL_CASE(O, D)                                                                                      \
     if (order == O && dim == D)                                                                                \
         launch_locate<O, D>(ctx, k, npoints, nn, gll_points_d, nelem, points_d, tolerance, snap_to_nearest, el, \
-                            coeffs_d, nm, visit);
+                            coeffs_d, nm, visit, qa, qb, counters, best_state, best_elem_state);
         MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
 #undef MM_GLL_CASE
         mm_stage_end(ctx, MM_STAGE_LOCATE);
