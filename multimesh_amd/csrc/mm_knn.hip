@@ -284,11 +284,11 @@ __device__ __forceinline__ double block_bound(const GridParams &g, double px, do
 
 // ---- generic path: ring expansion with a register-resident sorted list.  Always correct for any
 // density; used for the stragglers the fast kernel hands over (and for k > 32).
-template <int K>
+template <int K, typename IDX>
 __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, const int *__restrict__ cell_start,
                                               const double *__restrict__ sorted_xyz,
                                               const double *__restrict__ pts,
-                                              int ndim, int kout, i64 *__restrict__ idx_out,
+                                              int ndim, int kout, IDX *__restrict__ idx_out,
                                               double *__restrict__ dist_out, i64 i)
 {
     const double px = pts[i * ndim];
@@ -380,18 +380,18 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         if (s < kout) {
-            idx_out[i * kout + s] = (i64)best.id[s];
+            idx_out[i * kout + s] = (IDX)best.id[s];
             if (dist_out) dist_out[i * kout + s] = sqrt(best.d[s]);
         }
     }
 }
 
-template <int K>
+template <int K, typename IDX>
 __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsrc,
                                                            const int *__restrict__ cell_start,
                                                            const double *__restrict__ sorted_xyz,
                                                            const double *__restrict__ pts, i64 npts, int ndim,
-                                                           int kout, i64 *__restrict__ idx_out,
+                                                           int kout, IDX *__restrict__ idx_out,
                                                            double *__restrict__ dist_out,
                                                            const int *__restrict__ list,
                                                            const int *__restrict__ list_count)
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
     const i64 total = list ? (i64)*list_count : npts;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
-        knn_query_one<K>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
+        knn_query_one<K, IDX>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
                          list ? (i64)list[q] : q);
 }
 
@@ -464,14 +464,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int K, int CAP>
+template <int K, int CAP, typename IDX>
 __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 nsrc,
                                                             const int *__restrict__ cell_start,
                                                             const double *__restrict__ sorted_xyz,
                                                              const double *__restrict__ pts, int ndim, int kout,
                                                             const int *__restrict__ tstart,
                                                             const double *__restrict__ tsorted,
-                                                            i64 *__restrict__ idx_out,
+                                                            IDX *__restrict__ idx_out,
                                                             double *__restrict__ dist_out,
                                                             int *__restrict__ fb_list, int *__restrict__ fb_count,
                                                             int dbg_stop)
@@ -812,9 +812,14 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
         if (dbg_stop == 10) return;
         if (valid && !hand_over) {
             // the group's lanes write the target's row side by side (coalesced 8-byte stores)
-            i64 *row = idx_out + i * kout;
+            IDX *row = idx_out + i * kout;
             double *drow = dist_out ? dist_out + i * kout : nullptr;
-            if ((kout & 1) == 0) {
+            if (sizeof(IDX) == 4 && (kout & 3) == 0) {
+                // int32 rows (fused pipeline): 16-byte stores of four ids
+                for (int e = 4 * sl; e < kout; e += 4 * S)
+                    *reinterpret_cast<int4 *>(row + e) =
+                        make_int4(s_bx[e][tg], s_bx[e + 1][tg], s_bx[e + 2][tg], s_bx[e + 3][tg]);
+            } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
                 // 16-byte stores (rows are 16-byte aligned when k is even): fewer, fuller writes
                 for (int e = 2 * sl; e < kout; e += 2 * S) {
                     *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_bx[e][tg], (i64)s_bx[e + 1][tg]);
@@ -823,10 +828,12 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
                 }
             } else {
                 for (int e = sl; e < kout; e += S) {
-                    row[e] = (i64)s_bx[e][tg];
+                    row[e] = (IDX)s_bx[e][tg];
                     if (drow) drow[e] = sqrt(s_bd[e][tg]);
                 }
             }
+            if (sizeof(IDX) == 4 && (kout & 3) == 0 && drow)
+                for (int e = sl; e < kout; e += S) drow[e] = sqrt(s_bd[e][tg]);
         }
         if (dbg_stop == 11) return;
         if (valid && sl == 0) {
@@ -861,20 +868,20 @@ __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__re
                  ndim > 2 ? pts[t * ndim + 2] : 0.0, (int)t);
 }
 
-template <int K>
+template <int K, typename IDX>
 void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                    int kout, i64 *idx, double *dist, const int *list, const int *list_count)
+                    int kout, IDX *idx, double *dist, const int *list, const int *list_count)
 {
     i64 grid = (npts + kBlock - 1) / kBlock;
     if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
-    hipLaunchKernelGGL((knn_query_kernel<K>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
+    hipLaunchKernelGGL((knn_query_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
                        ix->cell_start, ix->sorted_xyz, pts, npts, ix->ndim, kout, idx, dist, list,
                        list_count);
 }
 
-template <int K>
+template <int K, typename IDX>
 void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                 int kout, const int *tstart, const double *tsorted, i64 *idx, double *dist,
+                 int kout, const int *tstart, const double *tsorted, IDX *idx, double *dist,
                  int *fb_list, int *fb_count)
 {
     constexpr int CAP = K + 12;
@@ -883,10 +890,10 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     const i64 cols = (i64)ix->dims[0] * ix->dims[1];
     const i64 cell_grid = 8 * ((cols + 7) / 8) * ix->dims[2];
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
-    hipLaunchKernelGGL((knn_cell_kernel<K, CAP>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
+    hipLaunchKernelGGL((knn_cell_kernel<K, CAP, IDX>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
                        ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
     mm_stage_end(ctx, MM_STAGE_KNN_CELL);
-    launch_generic<K>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
+    launch_generic<K, IDX>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
 
 GridParams params_of(const mm_knn_index *ix)
@@ -1057,8 +1064,9 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     return MM_OK;
 }
 
-int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, i64 *idx_d,
-                      double *dist_d)
+template <typename IDX>
+static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, IDX *idx_d,
+                           double *dist_d)
 {
     if (npts == 0 || k == 0) return MM_OK;
     MM_REQUIRE(npts < (i64)0x7fffffff, "too many targets for one query");
@@ -1066,8 +1074,8 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
     const int kout = (int)k;
     if (k > 32) {
         // long lists: generic ring-expansion kernel for every target
-        if (k <= 40) launch_generic<40>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
-        else launch_generic<MM_KNN_MAX_K>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        if (k <= 40) launch_generic<40, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        else launch_generic<MM_KNN_MAX_K, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
         MM_HIP_CHECK(hipGetLastError());
         return MM_OK;
     }
@@ -1103,14 +1111,14 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
     hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, ix->ndim,
                        start, tsorted);
 
-    if (k <= 1) launch_fast<1>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 2) launch_fast<2>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 4) launch_fast<4>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 8) launch_fast<8>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 16) launch_fast<16>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 20) launch_fast<20>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 25) launch_fast<25>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else launch_fast<32>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    if (k <= 1) launch_fast<1, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 2) launch_fast<2, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 4) launch_fast<4, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 8) launch_fast<8, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 16) launch_fast<16, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 20) launch_fast<20, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else if (k <= 25) launch_fast<25, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
+    else launch_fast<32, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
     MM_HIP_CHECK(hipGetLastError());
     if (getenv("MM_KNN_DEBUG")) {
         int h = 0;
@@ -1120,6 +1128,15 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
                 100.0 * h / (double)npts);
     }
     return MM_OK;
+}
+
+// idx_is_int32: the fused pipeline keeps its candidate lists as int32 (half the bytes); the public
+// mm_knn_query writes int64 like cKDTree.
+int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
+                      double *dist_d, bool idx_is_int32)
+{
+    if (idx_is_int32) return knn_query_typed<int>(ctx, ix, pts_d, npts, k, (int *)idx_d, dist_d);
+    return knn_query_typed<i64>(ctx, ix, pts_d, npts, k, (i64 *)idx_d, dist_d);
 }
 
 extern "C" int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, int64_t ndim, mm_knn_index **out)
@@ -1146,7 +1163,7 @@ extern "C" int mm_knn_query(mm_context *ctx, const mm_knn_index *index, const do
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
-    int rc = mm_knn_query_impl(ctx, index, pts_d, npts, k, (i64 *)idx_d, dist_d);
+    int rc = mm_knn_query_impl(ctx, index, pts_d, npts, k, idx_d, dist_d, false);
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     return rc;
 }

@@ -210,9 +210,9 @@ __device__ __forceinline__ void store_row(i64 *__restrict__ enc, double *__restr
     }
 }
 
-template <bool EXODUS>
+template <bool EXODUS, typename IDX>
 __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
-                                                          const i64 *__restrict__ nn,
+                                                          const IDX *__restrict__ nn,
                                                           const i64 *__restrict__ conn, i64 nelem,
                                                           i64 *__restrict__ enc,
                                                           const double *__restrict__ nodes,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                                                           const double *__restrict__ pts,
                                                           unsigned long long *__restrict__ nfailed,
                                                           const int *__restrict__ list,
-                                                          const int *__restrict__ list_count)
+                                                          const int *__restrict__ list_count, int zero_failed)
 {
     // list != null: only the queued targets (left over by the fast passes), grid-stride
     const i64 total = list ? (i64)*list_count : npoints;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
         Corners c;
         double xi[3], wt[8];
         for (i64 j = 0; j < k; ++j) {
-            const i64 elem = nn[i * k + j];
+            const i64 elem = (i64)nn[i * k + j];
             if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
             load_corners<EXODUS>(conn, nodes, elem, c);
             if (newton_hex8(px, py, pz, c.x, c.y, c.z, xi) && in_hull(xi)) {
@@ -267,6 +267,16 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                 }
             }
             failed = !ok;
+            if (failed && zero_failed) {
+                // fused pipeline: its private enc/w are not pre-zeroed, failed rows must read as zero
+                longlong2 *e2 = reinterpret_cast<longlong2 *>(enc + i * 8);
+                double2 *w2 = reinterpret_cast<double2 *>(w + i * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e2[q] = make_longlong2(0, 0);
+                    w2[q] = make_double2(0.0, 0.0);
+                }
+            }
         }
     }
     const unsigned long long mask = __ballot(failed);
@@ -288,8 +298,8 @@ constexpr int kPassIters = 10;
 constexpr int kPassBlock = 256;
 constexpr int kWaveQueue = 256;   // LDS entries per wave; flushed when more than kWaveQueue - 64 are held
 
-template <bool EXODUS>
-__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+template <bool EXODUS, typename IDX>
+__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  i64 *__restrict__ enc,
                                                                  const double *__restrict__ nodes,
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point
             bool have = false;
             for (; j < k; ++j) {
-                const i64 elem = nn[i * k + j];
+                const i64 elem = (i64)nn[i * k + j];
                 if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
                 load_corners<EXODUS>(conn, nodes, elem, c);
                 double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
@@ -405,9 +415,10 @@ __global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restri
 // Launch the whole locate stage on ctx->stream (no synchronisation).  Scratch: two pass queues,
 // the slow list and their counters come from the context's scratch pool, so this must be the only
 // scratch user between mm_scratch_begin calls of the caller -- it calls mm_scratch_begin itself.
-int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const i64 *conn, i64 nelem,
-                          int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
-                          i64 *d_nfailed)
+template <typename IDX>
+static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *nn, const i64 *conn, i64 nelem,
+                               int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
+                               i64 *d_nfailed, int zero_failed)
 {
     MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
     if (npoints == 0 || k == 0) return MM_OK;
@@ -442,10 +453,10 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, co
         dim3 g((unsigned)grid), b(block);
         if (p == 0) mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
         if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
                                nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
         else
-            hipLaunchKernelGGL((locate_pass_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
                                nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
         if (p == 0) mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     }
@@ -461,14 +472,27 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, co
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
         if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_hex8_kernel<true>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count);
+            hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
         else
-            hipLaunchKernelGGL((locate_hex8_kernel<false>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count);
+            hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
+                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
     }
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
+}
+
+// nn_is_int32 / zero_failed: the fused pipeline's int32 candidate lists and un-zeroed private
+// enc/w (failed rows are zeroed by the reference-order kernel, the only place a point can fail).
+int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32, const i64 *conn,
+                          i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
+                          i64 *d_nfailed, int zero_failed)
+{
+    if (nn_is_int32)
+        return launch_locate_typed<int>(ctx, k, npoints, (const int *)nn, conn, nelem, conn_is_exodus, enc, nodes, w,
+                                        pts, d_nfailed, zero_failed);
+    return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, enc, nodes, w, pts,
+                                    d_nfailed, zero_failed);
 }
 
 extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, const int64_t *nn_d,
@@ -483,8 +507,8 @@ extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, c
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
-    int rc = mm_launch_locate_hex8(ctx, k, npoints, (const i64 *)nn_d, (const i64 *)conn_d, nelem,
-                                   conn_is_exodus, (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters);
+    int rc = mm_launch_locate_hex8(ctx, k, npoints, nn_d, false, (const i64 *)conn_d, nelem, conn_is_exodus,
+                                   (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters, 0);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) return rc;
     MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost,

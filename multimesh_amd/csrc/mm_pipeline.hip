@@ -7,8 +7,8 @@
 
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
                       bool use_context_buffers);
-int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, i64 *idx_d,
-                      double *dist_d);
+int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
+                      double *dist_d, bool idx_is_int32);
 void mm_clear_status(void);
 
 // -----------------------------------------------------------------------------------------
@@ -36,7 +36,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     // Intermediates come from the context's grow-only buffer cache: after the first call with a
     // given problem size there is no allocation, free or extra synchronisation in here.
     double *cen = nullptr;
-    i64 *nn = nullptr;
+    int *nn = nullptr;  // candidate lists stay int32 inside the pipeline (half the bytes of the public int64)
     i64 *enc = (i64 *)enc_d;
     double *w = w_d;
     mm_knn_index *index = nullptr;
@@ -52,16 +52,14 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     } while (0)
 
     rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
-    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)k * sizeof(i64), (void **)&nn);
+    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn);
     if (rc == MM_OK && !enc) rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * 8 * sizeof(i64), (void **)&enc);
     if (rc == MM_OK && !w) rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * 8 * sizeof(double), (void **)&w);
     if (rc != MM_OK) { result = rc; goto done; }
 
     // rows of failed points must read as zero (the reference's callers zero-initialise,
-    // scripts/cli.py:77-78)
-    e = hipMemsetAsync(enc, 0, (size_t)npoints * 8 * sizeof(i64), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(w, 0, (size_t)npoints * 8 * sizeof(double), ctx->stream);
-    if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_HIP, hipGetErrorString(e));
+    // scripts/cli.py:77-78): the reference-order locate kernel, the only place a point can fail,
+    // zeroes them (no 1.3 GB memset up front)
 
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
     rc = mm_launch_centroid(ctx, 3, nelem, 8, (const i64 *)conn_d, nodes_d, cen);
@@ -74,13 +72,13 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
-    rc = mm_knn_query_impl(ctx, index, points_d, npoints, k, nn, nullptr);
+    rc = mm_knn_query_impl(ctx, index, points_d, npoints, k, nn, nullptr, true);
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
-    rc = mm_launch_locate_hex8(ctx, k, npoints, nn, (const i64 *)conn_d, nelem, /*exodus=*/1, enc, nodes_d, w,
-                               points_d, ctx->d_counters);
+    rc = mm_launch_locate_hex8(ctx, k, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
+                               nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) { result = rc; goto done; }
 
