@@ -23,6 +23,7 @@
 #include <new>
 
 #include "mm_common.h"
+#include <cstring>
 
 namespace {
 
@@ -854,6 +855,420 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
     }
 }
 
+// ---- fast path, 3-D grids: the cell kernel's rounds over a STRIP of kStripZ cells along z --------
+// The cell kernel pays its fixed costs per cell: a workgroup launch, the metadata loads, staging
+// all 27 neighbour cells (of which 18 are shared with the next cell up), and -- for the ~40 % of
+// cells holding more than 8 targets -- a second, nearly empty round.  Here one wave owns kStripZ
+// consecutive cells of a column:
+//   tile   : the strip's cells and their neighbours, (kStripZ+2) layers x 9 columns, staged once and
+//            stored LAYER-major, so the 27 cells around a target's cell are one contiguous window
+//            [layer(cz-1), layer(cz+2)) of the tile; coordinates relative to the strip's corner.
+//   rounds : the strip's targets are taken 8 at a time regardless of their cell (each group walks
+//            its own target's window); the last round of a strip widens the split (S = 16..64
+//            lanes per target) so that a round for one or two left-over targets is short.
+// Everything inside a round (P1 histogram, jb, P2 list, exact fp64, P3 rank sort, error bound) is the
+// cell kernel's, see there; only the fp32 rounding bound E uses the strip's extent in z.
+constexpr int kStripZ = 3;
+constexpr int kStripLayers = kStripZ + 2;
+constexpr int kStripTileCap = 416;   // 45 cells x ~8 expected = 360
+
+template <int K, int CAP, typename IDX>
+__global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 nsrc,
+                                                             const int *__restrict__ cell_start,
+                                                             const double *__restrict__ sorted_xyz, int ndim,
+                                                             int kout, const int *__restrict__ tstart,
+                                                             const double *__restrict__ tsorted,
+                                                             IDX *__restrict__ idx_out,
+                                                             double *__restrict__ dist_out,
+                                                             int *__restrict__ fb_list, int *__restrict__ fb_count,
+                                                             int dbg_stop)
+{
+    static_assert(CAP <= 64, "rank mask is 64 bits");
+    __shared__ float4 tile[kStripTileCap + 1];                  // +1: far-away sentinel entry
+    // Two pairs of arrays are never live together and share their memory (more waves per CU):
+    //   s_pk (P1 -> P2: bucket numbers of each lane's slots)  |  s_bd (exact -> output: distances)
+    //   s_hist (P1 -> scan: histogram, last row = sink)       |  s_bx (P2 -> output: positions/ids)
+    // Each hand-over is separated by a wave_sync() from the last use of the other member.
+    constexpr int kPkBytes = (kSlots / 4) * kWave * 4, kBdBytes = CAP * kMaxGroups * 8;
+    constexpr int kHistBytes = (kHistBuckets + 1) * kMaxGroups * 4, kBxBytes = CAP * kMaxGroups * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem0[kPkBytes > kBdBytes ? kPkBytes : kBdBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem1[kHistBytes > kBxBytes ? kHistBytes : kBxBytes];
+    unsigned (*const s_pk)[kWave] = reinterpret_cast<unsigned (*)[kWave]>(s_mem0);
+    double (*const s_bd)[kMaxGroups] = reinterpret_cast<double (*)[kMaxGroups]>(s_mem0);
+    unsigned (*const s_hist)[kMaxGroups] = reinterpret_cast<unsigned (*)[kMaxGroups]>(s_mem1);
+    int (*const s_bx)[kMaxGroups] = reinterpret_cast<int (*)[kMaxGroups]>(s_mem1);
+    __shared__ int s_jb[kMaxGroups];
+    __shared__ int s_cnt[kMaxGroups];
+    __shared__ unsigned long long s_seen[kMaxGroups];
+    __shared__ int s_layer[kStripLayers + 1];
+
+    const int lane = threadIdx.x;
+    // XCD-aware strip -> workgroup map (see knn_cell_kernel): XCD x owns a slab of columns
+    const int ncols = g.nx * g.ny;
+    const int cols_per_xcd = (ncols + 7) / 8;
+    const int nstrips = (g.nz + kStripZ - 1) / kStripZ;
+    const int xcd = blockIdx.x & 7;
+    const int m = blockIdx.x >> 3;
+    const int colm = m / nstrips;
+    const int col = xcd * cols_per_xcd + colm;
+    if (colm >= cols_per_xcd || col >= ncols) return;
+    const int strip = m - colm * nstrips;
+    const int cx = col / g.ny, cy = col - cx * g.ny;
+    const int cz0 = strip * kStripZ, cz1 = min(cz0 + kStripZ, g.nz);
+    const int t0 = tstart[col * g.nz + cz0];
+    const int t1 = tstart[col * g.nz + cz1];
+    const int tn = t1 - t0;
+    if (tn == 0) return;
+    const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
+    const int nlayers = zb - za + 1;
+    const int ntc = nlayers * 9;
+    const double ox = g.lox + (double)cx * g.hx;
+    const double oy = g.loy + (double)cy * g.hy;
+    const double oz = g.loz + (double)cz0 * g.hz;
+
+    // first round's targets: cell-sorted copies of the coordinates (contiguous, no indirection);
+    // issued before the tile loads so that both are in flight together
+    double npx, npy, npz, npw;
+    {
+        int S1 = kWave;
+        while (S1 > kWave / kMaxGroups && kWave / S1 < tn) S1 >>= 1;
+        const int tg1 = lane / S1;
+        const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (tg1 < tn ? tg1 : 0)) * kRec);
+        const double2 xy = r2[0], zw = r2[1];
+        npx = xy.x;
+        npy = xy.y;
+        npz = zw.x;
+        npw = zw.y;
+    }
+
+    // ---- stage the tile: lane l copies cell l of the (layer, column) list
+    int total;
+    {
+        const int layer = lane / 9, c = lane - layer * 9;
+        const int ix = cx + c / 3 - 1, iy = cy + (c - (c / 3) * 3) - 1;
+        const bool inside = lane < ntc && (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny;
+        int s0 = 0, cnt = 0;
+        if (inside) {
+            const int cellid = (ix * g.ny + iy) * g.nz + za + layer;
+            s0 = cell_start[cellid];
+            cnt = cell_start[cellid + 1] - s0;
+        }
+        int incl = cnt;
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        total = __shfl(incl, kWave - 1);
+        const int off = incl - cnt;
+        if (lane < ntc && c == 0) s_layer[layer] = off;
+        if (lane == 0) s_layer[nlayers] = total;
+        if (total <= kStripTileCap) {
+            for (int q = 0; __any(q < cnt); q += 2) {
+                double2 xy[2], zw[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const i64 s = (i64)s0 + min(q + u, max(cnt - 1, 0));
+                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
+                    xy[u] = r2[0];
+                    zw[u] = r2[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (q + u < cnt)
+                        tile[off + q + u] = make_float4((float)(xy[u].x - ox), (float)(xy[u].y - oy),
+                                                        (float)(zw[u].x - oz), __int_as_float(s0 + q + u));
+            }
+            if (lane == 0) tile[total] = make_float4(1e30f, 1e30f, 1e30f, 0.f);  // slots past a window read this
+        }
+    }
+    if (total > kStripTileCap || total < kout) {
+        // the whole strip goes to the generic kernel
+        for (int q = lane; q < tn; q += kWave)
+            fb_list[atomicAdd(fb_count, 1)] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+        return;
+    }
+    wave_sync();  // tile and layer table staged
+    if (dbg_stop == 1) return;  // diagnostic builds only (MM_KNN_DBG_STOP): time the phases
+
+    // widest window of the strip's cells (uniform loop bounds), block volume per layer
+    int maxwin = 0;
+    for (int cz = cz0; cz < cz1; ++cz)
+        maxwin = max(maxwin, s_layer[min(cz + 1, zb) - za + 1] - s_layer[max(cz - 1, za) - za]);
+    maxwin = min(maxwin, kTileCap);
+    int dims = 0;
+    float vol_layer = 1.f;
+    {
+        const int bx = min(cx + 1, g.nx - 1) - max(cx - 1, 0) + 1;
+        const int by = min(cy + 1, g.ny - 1) - max(cy - 1, 0) + 1;
+        if (g.nx > 1) { ++dims; vol_layer *= (float)bx * (float)g.hx; }
+        if (g.ny > 1) { ++dims; vol_layer *= (float)by * (float)g.hy; }
+        if (g.nz > 1) { ++dims; vol_layer *= (float)g.hz; }
+    }
+    constexpr int U = 4;
+    constexpr double kU = 0x1p-24;
+
+    int tpw = 0;
+    for (int r0 = 0; r0 < tn; r0 += tpw) {
+        // lanes per target: the widest split whose round still covers the remaining targets
+        const int rem = tn - r0;
+        int S = kWave;
+        while (S > kWave / kMaxGroups && kWave / S < rem) S >>= 1;
+        tpw = kWave / S;
+        const int tg = lane / S;         // this lane's target slot in the round
+        const int sl = lane % S;         // this lane's slice of the window
+        const int nbatch = (maxwin + U * S - 1) / (U * S);
+        const int bpl = kHistBuckets / S;  // histogram buckets per lane in the scan (S = 64 -> 1)
+        const bool valid = tg < rem;
+        const double px = valid ? npx : ox;
+        const double py = valid ? npy : oy;
+        const double pz = valid ? npz : oz;
+        const i64 i = valid ? (i64)record_id(npw) : 0;  // the target's original index
+        if (rem > tpw) {
+            // next round's targets (its split may be wider), in flight during this round
+            const int rem2 = rem - tpw;
+            int S2 = kWave;
+            while (S2 > kWave / kMaxGroups && kWave / S2 < rem2) S2 >>= 1;
+            const int tg2 = lane / S2;
+            const double2 *r2 =
+                reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + r0 + tpw + (tg2 < rem2 ? tg2 : 0)) * kRec);
+            const double2 xy = r2[0], zw = r2[1];
+            npx = xy.x;
+            npy = xy.y;
+            npz = zw.x;
+            npw = zw.y;
+        }
+        for (int q = lane; q < (kHistBuckets + 1) * kMaxGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
+        if (lane < kMaxGroups) {
+            s_jb[lane] = kHistBuckets;
+            s_seen[lane] = 0ull;
+        }
+        const int czl = min(max(cell_coord(pz, g.loz, g.ihz, g.nz), cz0), cz1 - 1);
+        const int l0 = max(czl - 1, za) - za, l1 = min(czl + 1, zb) - za + 1;
+        const int ws = s_layer[l0];
+        const int we = valid ? s_layer[l1] : ws;
+        const float tx = (float)(px - ox), ty = (float)(py - oy), tz = (float)(pz - oz);
+        const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
+                                     (double)(kStripZ + 1) * g.hz);
+        // histogram range from the density of the target's own window: the ball holding k of the
+        // window's sources has r^d = (k/count) * V_block / c_d; buckets are uniform in r^2 over
+        // [0, 2.2 r^2).  Only a heuristic range, so fast exp2/log2 are fine.
+        float scale;
+        {
+            const float vol = g.nz > 1 ? vol_layer * (float)(l1 - l0) : vol_layer;
+            const float frac = (float)kout / (float)max(we - ws, 1);
+            float r2;
+            if (dims == 3) r2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(frac * vol * (1.f / 4.18879f)) * (2.f / 3.f));
+            else if (dims == 2) r2 = frac * vol * (1.f / 3.14159f);
+            else if (dims == 1) { const float r = frac * vol * 0.5f; r2 = r * r; }
+            else r2 = 1.f;
+            scale = (float)kHistBuckets / (2.2f * r2);
+        }
+        bool hand_over = !(scale > 0.f && scale < INFINITY) || we - ws < kout || we - ws > kTileCap;
+        if (!(scale > 0.f && scale < INFINITY)) scale = 1.f;
+        wave_sync();  // counters cleared
+
+        // ---- P1: histogram of fp32 squared distances; the bucket numbers of a lane's slots are
+        // kept (4 per word) in LDS for P2.  Slots past the end of the window read the far-away
+        // sentinel (last bucket, never counted nor collected).
+        for (int m = 0; m < nbatch; ++m) {
+            float4 q4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = ws + sl + (m * U + u) * S;
+                q4[u] = tile[j < we ? j : total];
+            }
+            unsigned packed = 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float fx = q4[u].x - tx, fy = q4[u].y - ty, fz = q4[u].z - tz;
+                const float a = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                const int b = (int)fminf(a * scale, (float)(kHistBuckets - 1));  // NaN -> last bucket
+                if (b < kHistBuckets - 1) atomicAdd(&s_hist[b][tg], 1u);
+                packed |= (unsigned)b << (8 * u);
+            }
+            s_pk[m][lane] = packed;
+        }
+        wave_sync();
+        if (dbg_stop == 2) return;
+
+        // ---- jb = first bucket whose running count reaches k
+        {
+            int mine = 0;
+            for (int q = 0; q < bpl; ++q) mine += (int)s_hist[sl * bpl + q][tg];
+            const int incl = group_scan(mine, sl, S);
+            int run_count = incl - mine;
+            if (run_count < kout && incl >= kout) {
+                for (int q = 0; q < bpl; ++q) {
+                    run_count += (int)s_hist[sl * bpl + q][tg];
+                    if (run_count >= kout) {
+                        s_jb[tg] = sl * bpl + q;
+                        break;
+                    }
+                }
+            }
+        }
+        wave_sync();
+        const int jb = s_jb[tg];
+        if (jb >= kHistBuckets - 2) hand_over = true;  // k-th distance beyond the histogram range
+        {
+            // every exact k-nearest candidate must land in a bucket <= jb+1 (cell kernel's header)
+            const double e1 = (double)(jb + 1) / (double)scale;
+            const double e2 = (double)(jb + 2) / (double)scale;
+            const double D = sqrt(e1) * (1.0 + 4.0 * kU) + E;
+            const double D2 = D * (1.0 + 4.0 * kU) + E;
+            if (!(D2 * D2 * (1.0 + 8.0 * kU) < e2)) hand_over = true;
+        }
+        if (dbg_stop == 3) { if (jb == 77) fb_list[0] = jb; return; }
+
+        // ---- P2: candidates in buckets <= jb+1 go to the target's list
+        unsigned qmask = 0u;
+        for (int m = 0; m < nbatch; ++m) {
+            const unsigned packed = s_pk[m][lane];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = (int)((packed >> (8 * u)) & 0xffu);
+                qmask |= (b <= jb + 1 ? 1u : 0u) << (m * U + u);
+            }
+        }
+        if (hand_over) qmask = 0u;
+        const int mycnt = __popc(qmask);
+        const int incl = group_scan(mycnt, sl, S);
+        const int n = __shfl(incl, tg * S + S - 1);
+        int pos = incl - mycnt;
+        while (qmask) {
+            const int slot = __ffs(qmask) - 1;
+            qmask &= qmask - 1u;
+            if (pos < CAP) s_bx[pos][tg] = __float_as_int(tile[ws + sl + slot * S].w);
+            ++pos;
+        }
+        if (sl == 0) s_cnt[tg] = n;
+        wave_sync();
+        if (dbg_stop == 4) return;
+        if (n > CAP) hand_over = true;
+        int nmax = 0;
+        for (int q = 0; q < tpw; ++q) nmax = max(nmax, min(s_cnt[q], CAP));
+        const int owned = (nmax + S - 1) / S;  // list entries per lane: sl, sl+S, ...
+
+        // ---- exact fp64 distance (reference arithmetic) and source id of the owned entries
+        constexpr int MAXE = (CAP + 7) / 8;
+        double ed[MAXE];
+        int ei[MAXE], rank[MAXE];
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            const bool live = o < owned && e < n && e < CAP;
+            ed[o] = INFINITY;
+            ei[o] = 0x7fffffff;
+            rank[o] = 0;
+            if (live) {
+                const i64 s = (i64)s_bx[e][tg];
+                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
+                const double2 xy = r2[0], zw = r2[1];
+                const double dx = xy.x - px;
+                const double dy = xy.y - py;
+                const double dz = zw.x - pz;
+                double d2 = dx * dx;
+                d2 = d2 + dy * dy;
+                if (ndim > 2) d2 = d2 + dz * dz;
+                ed[o] = d2;
+                ei[o] = record_id(zw.y);
+                s_bd[e][tg] = d2;
+                s_bx[e][tg] = ei[o];
+            }
+        }
+        wave_sync();
+        if (dbg_stop == 5) return;
+
+        // ---- P3: rank by exact d2
+        for (int j0 = 0; j0 < nmax; j0 += U) {
+            double dj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[min(j0 + u, CAP - 1)][tg] : INFINITY;
+#pragma unroll
+            for (int o = 0; o < MAXE; ++o) {
+                if (o < owned) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) rank[o] += dj[u] < ed[o] ? 1 : 0;
+                }
+            }
+        }
+        // distinct distances <=> the ranks are a permutation of 0..n-1
+        const unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            if (o < owned && e < n && e < CAP) atomicOr(&s_seen[tg], 1ull << rank[o]);
+        }
+        wave_sync();
+        const bool tied = valid && !hand_over && s_seen[tg] != full;
+        if (__any(tied)) {
+            // bit-equal distances somewhere in this round: redo the ranks lexicographically
+#pragma unroll
+            for (int o = 0; o < MAXE; ++o) rank[o] = 0;
+            for (int j = 0; j < nmax; ++j) {
+                const bool live = j < n;
+                const double dj = live ? s_bd[min(j, CAP - 1)][tg] : INFINITY;
+                const int ij = live ? s_bx[min(j, CAP - 1)][tg] : 0x7fffffff;
+#pragma unroll
+                for (int o = 0; o < MAXE; ++o)
+                    if (o < owned) rank[o] += before(dj, ij, ed[o], ei[o]) ? 1 : 0;
+            }
+            wave_sync();
+        }
+        if (dbg_stop == 6) return;
+        // sorted order back into the list (every lane has finished reading it)
+#pragma unroll
+        for (int o = 0; o < MAXE; ++o) {
+            const int e = sl + o * S;
+            if (o < owned && e < n && e < CAP) {
+                s_bd[rank[o]][tg] = ed[o];
+                s_bx[rank[o]][tg] = ei[o];
+            }
+        }
+        wave_sync();
+        if (valid && !hand_over) {
+            // the group's lanes write the target's row side by side
+            IDX *row = idx_out + i * kout;
+            double *drow = dist_out ? dist_out + i * kout : nullptr;
+            if (sizeof(IDX) == 4 && (kout & 3) == 0) {
+                for (int e = 4 * sl; e < kout; e += 4 * S)
+                    *reinterpret_cast<int4 *>(row + e) =
+                        make_int4(s_bx[e][tg], s_bx[e + 1][tg], s_bx[e + 2][tg], s_bx[e + 3][tg]);
+            } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
+                for (int e = 2 * sl; e < kout; e += 2 * S) {
+                    *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_bx[e][tg], (i64)s_bx[e + 1][tg]);
+                    if (drow)
+                        *reinterpret_cast<double2 *>(drow + e) = make_double2(sqrt(s_bd[e][tg]), sqrt(s_bd[e + 1][tg]));
+                }
+            } else {
+                for (int e = sl; e < kout; e += S) {
+                    row[e] = (IDX)s_bx[e][tg];
+                    if (drow) drow[e] = sqrt(s_bd[e][tg]);
+                }
+            }
+            if (sizeof(IDX) == 4 && (kout & 3) == 0 && drow)
+                for (int e = sl; e < kout; e += S) drow[e] = sqrt(s_bd[e][tg]);
+        }
+        if (dbg_stop == 7) return;
+        if (valid && sl == 0) {
+            if (!hand_over) {
+                // could a nearer source sit outside the target's 3x3x3 block?
+                const bool all_x = (cx - 1 <= 0) && (cx + 1 >= g.nx - 1);
+                const bool all_y = (cy - 1 <= 0) && (cy + 1 >= g.ny - 1);
+                const bool all_z = (czl - 1 <= 0) && (czl + 1 >= g.nz - 1);
+                if (!(all_x && all_y && all_z)) {
+                    const double kth = s_bd[kout - 1][tg];
+                    const double bound = block_bound(g, px, py, pz, cx, cy, czl, 1);
+                    if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
+                }
+            }
+            if (hand_over) fb_list[atomicAdd(fb_count, 1)] = (int)i;
+        }
+        wave_sync();  // before the next round clears the counters
+        if (dbg_stop == 8) return;
+    }
+}
+
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
 __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__restrict__ cell_of, i64 npts,
                                                                 const double *__restrict__ pts, int ndim,
@@ -889,9 +1304,20 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     // 8 XCD slabs of ceil(columns/8) cell columns each (see the kernel's workgroup map)
     const i64 cols = (i64)ix->dims[0] * ix->dims[1];
     const i64 cell_grid = 8 * ((cols + 7) / 8) * ix->dims[2];
+    // strips along z need a grid that is deep in z; flat and 2-D grids keep the cell kernel
+    static const int force = getenv("MM_KNN_KERNEL") ? (strcmp(getenv("MM_KNN_KERNEL"), "strip") == 0 ? 1 : 2) : 0;
+    const bool use_strip = force == 1 || (force == 0 && ix->dims[2] >= 2 * kStripZ);
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
-    hipLaunchKernelGGL((knn_cell_kernel<K, CAP, IDX>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
-                       ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
+    if (use_strip) {
+        const i64 nstrips = (ix->dims[2] + kStripZ - 1) / kStripZ;
+        const i64 strip_grid = 8 * ((cols + 7) / 8) * nstrips;
+        hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX>), dim3((unsigned)strip_grid), dim3(kWave), 0, ctx->stream, g,
+                           ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist,
+                           fb_list, fb_count, dbg_stop);
+    } else {
+        hipLaunchKernelGGL((knn_cell_kernel<K, CAP, IDX>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
+                           ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
+    }
     mm_stage_end(ctx, MM_STAGE_KNN_CELL);
     launch_generic<K, IDX>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
