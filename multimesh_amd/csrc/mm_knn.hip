@@ -868,9 +868,14 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
 //            lanes per target) so that a round for one or two left-over targets is short.
 // Everything inside a round (P1 histogram, jb, P2 list, exact fp64, P3 rank sort, error bound) is the
 // cell kernel's, see there; only the fp32 rounding bound E uses the strip's extent in z.
-constexpr int kStripZ = 3;
+#ifndef MM_STRIP_Z          // tuning builds only (make EXTRA="-DMM_STRIP_Z=4 -DMM_STRIP_CAP=496")
+#define MM_STRIP_Z 2
+#define MM_STRIP_CAP 352   // 36 cells x ~8 expected = 288, + 3 sigma
+#endif
+constexpr int kStripZ = MM_STRIP_Z;
 constexpr int kStripLayers = kStripZ + 2;
-constexpr int kStripTileCap = 416;   // 45 cells x ~8 expected = 360
+constexpr int kStripTileCap = MM_STRIP_CAP;
+static_assert(kStripLayers * 9 <= kWave, "one lane stages one tile cell");
 
 template <int K, int CAP, typename IDX>
 __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 nsrc,
@@ -884,7 +889,9 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                                                              int dbg_stop)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
-    __shared__ float4 tile[kStripTileCap + 1];                  // +1: far-away sentinel entry
+    // Slots past the end of the tile read the far-away sentinel behind it; slots past a window but
+    // inside the tile are sources of the next layer -- real candidates, just not needed.
+    __shared__ float4 tile[kStripTileCap + 1];
     // Two pairs of arrays are never live together and share their memory (more waves per CU):
     //   s_pk (P1 -> P2: bucket numbers of each lane's slots)  |  s_bd (exact -> output: distances)
     //   s_hist (P1 -> scan: histogram, last row = sink)       |  s_bx (P2 -> output: positions/ids)
@@ -978,7 +985,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                         tile[off + q + u] = make_float4((float)(xy[u].x - ox), (float)(xy[u].y - oy),
                                                         (float)(zw[u].x - oz), __int_as_float(s0 + q + u));
             }
-            if (lane == 0) tile[total] = make_float4(1e30f, 1e30f, 1e30f, 0.f);  // slots past a window read this
+            if (lane == 0) tile[total] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
         }
     }
     if (total > kStripTileCap || total < kout) {
@@ -1046,7 +1053,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         const int l0 = max(czl - 1, za) - za, l1 = min(czl + 1, zb) - za + 1;
         const int ws = s_layer[l0];
         const int we = valid ? s_layer[l1] : ws;
-        const float tx = (float)(px - ox), ty = (float)(py - oy), tz = (float)(pz - oz);
+        // an idle group's target is moved far away: all its pairs fall into the (uncounted) last bucket
+        const float tx = valid ? (float)(px - ox) : -1e30f, ty = (float)(py - oy), tz = (float)(pz - oz);
         const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
                                      (double)(kStripZ + 1) * g.hz);
         // histogram range from the density of the target's own window: the ball holding k of the
@@ -1073,10 +1081,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         for (int m = 0; m < nbatch; ++m) {
             float4 q4[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = ws + sl + (m * U + u) * S;
-                q4[u] = tile[j < we ? j : total];
-            }
+            for (int u = 0; u < U; ++u) q4[u] = tile[min(ws + sl + (m * U + u) * S, total)];
             unsigned packed = 0u;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1121,13 +1126,14 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (dbg_stop == 3) { if (jb == 77) fb_list[0] = jb; return; }
 
         // ---- P2: candidates in buckets <= jb+1 go to the target's list
+        // (four bucket numbers per word, each < 64: adding 126 - jb sets a byte's top bit exactly when
+        // its bucket is >= jb + 2, without carries; the multiply gathers the four flags)
         unsigned qmask = 0u;
-        for (int m = 0; m < nbatch; ++m) {
-            const unsigned packed = s_pk[m][lane];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int b = (int)((packed >> (8 * u)) & 0xffu);
-                qmask |= (b <= jb + 1 ? 1u : 0u) << (m * U + u);
+        {
+            const unsigned bias = (unsigned)(126 - min(jb, kHistBuckets)) * 0x01010101u;
+            for (int m = 0; m < nbatch; ++m) {
+                const unsigned keep = (~(s_pk[m][lane] + bias) & 0x80808080u) >> 7;
+                qmask |= (((keep * 0x00204081u) >> 21) & 0xfu) << (m * U);
             }
         }
         if (hand_over) qmask = 0u;
@@ -1306,7 +1312,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     const i64 cell_grid = 8 * ((cols + 7) / 8) * ix->dims[2];
     // strips along z need a grid that is deep in z; flat and 2-D grids keep the cell kernel
     static const int force = getenv("MM_KNN_KERNEL") ? (strcmp(getenv("MM_KNN_KERNEL"), "strip") == 0 ? 1 : 2) : 0;
-    const bool use_strip = force == 1 || (force == 0 && ix->dims[2] >= 2 * kStripZ);
+    const bool use_strip = force == 1 || (force == 0 && ix->dims[2] >= 6);
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     if (use_strip) {
         const i64 nstrips = (ix->dims[2] + kStripZ - 1) / kStripZ;
