@@ -83,9 +83,12 @@ void mm_stage_end(mm_context *ctx, int stage);
 // ---- internal launchers (device pointers, no synchronisation) -------------------------
 int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,
                        const double *points, double *out);
+// enc/w: operator rows (may be null when out is given); fields [ncomp][nnodes] + out [npoints][ncomp]:
+// interpolated values formed at the acceptance point (the gather fused into the locate), or null
 int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32,
                           const i64 *conn, i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes,
-                          double *w, const double *pts, i64 *d_nfailed, int zero_failed);
+                          double *w, const double *pts, i64 *d_nfailed, int zero_failed,
+                          const double *fields, i64 nnodes, i64 ncomp, double *out);
 int mm_launch_gather(mm_context *ctx, const double *fields, i64 nsrc, i64 ncomp, const i64 *ids,
                      const double *w, i64 npoints, i64 P, double *out, int out_point_major);
 

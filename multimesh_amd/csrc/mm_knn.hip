@@ -874,6 +874,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
 #endif
 constexpr int kStripZ = MM_STRIP_Z;
 constexpr int kStripLayers = kStripZ + 2;
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kStripTileCap = MM_STRIP_CAP;
 static_assert(kStripLayers * 9 <= kWave, "one lane stages one tile cell");
 
@@ -889,21 +890,35 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                                                              int dbg_stop)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
-    // Slots past the end of the tile read the far-away sentinel behind it; slots past a window but
-    // inside the tile are sources of the next layer -- real candidates, just not needed.
-    __shared__ float4 tile[kStripTileCap + 1];
+    // The tile holds the sources in PAIRS, {x0,x1,y0,y1}{z0,z1,w0,w1} (w = position in the sorted
+    // array), so that P1 evaluates two candidates per packed-fp32 instruction.  Every layer starts
+    // at an even entry (an odd layer is padded with one far-away sentinel).  Slots past the end of
+    // the tile read the sentinel pair behind it; slots past a window but inside the tile are sources
+    // of the next layer -- real candidates, just not needed.
+    constexpr int kPairCap = kStripTileCap / 2;
+    __shared__ float4 tile_xy[kPairCap + 1];   // separate arrays: consecutive lanes, consecutive words
+    __shared__ float2 tile_z[kPairCap + 1];
+    __shared__ int2 tile_w[kPairCap + 1];      // only P2 looks at the positions
+    float *const txy = reinterpret_cast<float *>(tile_xy);
+    float *const tz_ = reinterpret_cast<float *>(tile_z);
+    int *const tw_ = reinterpret_cast<int *>(tile_w);
+    // Per-target arrays are laid out [group][entry] with strides that spread a group's lanes over
+    // the LDS banks (an [entry][group] layout puts the 8 lanes of a group on 2-4 banks).
     // Two pairs of arrays are never live together and share their memory (more waves per CU):
     //   s_pk (P1 -> P2: bucket numbers of each lane's slots)  |  s_bd (exact -> output: distances)
-    //   s_hist (P1 -> scan: histogram, last row = sink)       |  s_bx (P2 -> output: positions/ids)
+    //   s_hist (P1 -> scan: histogram, last column = sink)    |  s_bx (P2 -> output: positions/ids)
     // Each hand-over is separated by a wave_sync() from the last use of the other member.
-    constexpr int kPkBytes = (kSlots / 4) * kWave * 4, kBdBytes = CAP * kMaxGroups * 8;
-    constexpr int kHistBytes = (kHistBuckets + 1) * kMaxGroups * 4, kBxBytes = CAP * kMaxGroups * 4;
+    constexpr int kBdStride = CAP | 1;                 // doubles per group (odd)
+    constexpr int kBxStride = (CAP + 7) / 4 * 4;       // ints per group (rows stay 16-byte aligned)
+    constexpr int kHistStride = kHistBuckets + 1;      // words per group (odd)
+    constexpr int kPkBytes = (kSlots / 4) * kWave * 4, kBdBytes = kMaxGroups * kBdStride * 8;
+    constexpr int kHistBytes = kMaxGroups * kHistStride * 4, kBxBytes = kMaxGroups * kBxStride * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem0[kPkBytes > kBdBytes ? kPkBytes : kBdBytes];
     __shared__ __attribute__((aligned(16))) unsigned char s_mem1[kHistBytes > kBxBytes ? kHistBytes : kBxBytes];
     unsigned (*const s_pk)[kWave] = reinterpret_cast<unsigned (*)[kWave]>(s_mem0);
-    double (*const s_bd)[kMaxGroups] = reinterpret_cast<double (*)[kMaxGroups]>(s_mem0);
-    unsigned (*const s_hist)[kMaxGroups] = reinterpret_cast<unsigned (*)[kMaxGroups]>(s_mem1);
-    int (*const s_bx)[kMaxGroups] = reinterpret_cast<int (*)[kMaxGroups]>(s_mem1);
+    double (*const s_bd)[kBdStride] = reinterpret_cast<double (*)[kBdStride]>(s_mem0);
+    unsigned (*const s_hist)[kHistStride] = reinterpret_cast<unsigned (*)[kHistStride]>(s_mem1);
+    int (*const s_bx)[kBxStride] = reinterpret_cast<int (*)[kBxStride]>(s_mem1);
     __shared__ int s_jb[kMaxGroups];
     __shared__ int s_cnt[kMaxGroups];
     __shared__ unsigned long long s_seen[kMaxGroups];
@@ -965,8 +980,17 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             const int t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        total = __shfl(incl, kWave - 1);
-        const int off = incl - cnt;
+        // pad odd layers: entries of layer L shift by the number of odd layers below it
+        int pad = 0, pads_all = 0;
+        for (int L = 0; L < nlayers; ++L) {
+            const int end = __shfl(incl, 9 * L + 8);
+            const int beg = L > 0 ? __shfl(incl, 9 * L - 1) : 0;
+            const int odd = (end - beg) & 1;
+            if (L < layer) pad += odd;
+            pads_all += odd;
+        }
+        total = __shfl(incl, kWave - 1) + pads_all;
+        const int off = incl - cnt + pad;
         if (lane < ntc && c == 0) s_layer[layer] = off;
         if (lane == 0) s_layer[nlayers] = total;
         if (total <= kStripTileCap) {
@@ -981,11 +1005,28 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    if (q + u < cnt)
-                        tile[off + q + u] = make_float4((float)(xy[u].x - ox), (float)(xy[u].y - oy),
-                                                        (float)(zw[u].x - oz), __int_as_float(s0 + q + u));
+                    if (q + u < cnt) {
+                        const int e = off + q + u;
+                        const int at = (e >> 1) * 4 + (e & 1);
+                        txy[at] = (float)(xy[u].x - ox);
+                        txy[at + 2] = (float)(xy[u].y - oy);
+                        tz_[e] = (float)(zw[u].x - oz);
+                        tw_[e] = s0 + q + u;
+                    }
             }
-            if (lane == 0) tile[total] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+            // the sentinel that evens out an odd layer (written by the layer's last cell)
+            if (lane < ntc && c == 8 && ((off + cnt) & 1)) {
+                const int at = ((off + cnt) >> 1) * 4 + 1;
+                txy[at] = 1e30f;
+                txy[at + 2] = 1e30f;
+                tz_[off + cnt] = 1e30f;
+                tw_[off + cnt] = 0;
+            }
+            if (lane == 0) {
+                tile_xy[total >> 1] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                tile_z[total >> 1] = make_float2(1e30f, 1e30f);
+                tile_w[total >> 1] = make_int2(0, 0);
+            }
         }
     }
     if (total > kStripTileCap || total < kout) {
@@ -1075,21 +1116,36 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (!(scale > 0.f && scale < INFINITY)) scale = 1.f;
         wave_sync();  // counters cleared
 
-        // ---- P1: histogram of fp32 squared distances; the bucket numbers of a lane's slots are
-        // kept (4 per word) in LDS for P2.  Slots past the end of the window read the far-away
-        // sentinel (last bucket, never counted nor collected).
+        // ---- P1: histogram of fp32 squared distances (two candidates per packed instruction); the
+        // bucket numbers of a lane's slots are kept (4 per word) in LDS for P2.  Slot 4m+u of a lane
+        // is half (u & 1) of pair wsp + sl + (2m + u/2) * S.
+        const int wsp = ws >> 1, total_p = total >> 1;
+        const v2f tx2 = {tx, tx}, ty2 = {ty, ty}, tz2 = {tz, tz}, scale2 = {scale, scale};
         for (int m = 0; m < nbatch; ++m) {
-            float4 q4[U];
+            float4 qa[2];
+            float2 qb[2];
 #pragma unroll
-            for (int u = 0; u < U; ++u) q4[u] = tile[min(ws + sl + (m * U + u) * S, total)];
+            for (int h = 0; h < 2; ++h) {
+                const int pr = min(wsp + sl + (2 * m + h) * S, total_p);
+                qa[h] = tile_xy[pr];
+                qb[h] = tile_z[pr];
+            }
             unsigned packed = 0u;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float fx = q4[u].x - tx, fy = q4[u].y - ty, fz = q4[u].z - tz;
-                const float a = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-                const int b = (int)fminf(a * scale, (float)(kHistBuckets - 1));  // NaN -> last bucket
-                if (b < kHistBuckets - 1) atomicAdd(&s_hist[b][tg], 1u);
-                packed |= (unsigned)b << (8 * u);
+            for (int h = 0; h < 2; ++h) {
+                const v2f fx = v2f{qa[h].x, qa[h].y} - tx2;
+                const v2f fy = v2f{qa[h].z, qa[h].w} - ty2;
+                const v2f fz = v2f{qb[h].x, qb[h].y} - tz2;
+                const v2f a = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
+                const v2f sc = a * scale2;
+                // NaN -> last bucket (fminf returns the non-NaN operand).  The last bucket means
+                // "beyond the histogram range": most candidates land there, and counting them
+                // would serialise the LDS atomic on one address, so they are not counted.
+                const int b0 = (int)fminf(sc.x, (float)(kHistBuckets - 1));
+                const int b1 = (int)fminf(sc.y, (float)(kHistBuckets - 1));
+                if (b0 < kHistBuckets - 1) atomicAdd(&s_hist[tg][b0], 1u);
+                if (b1 < kHistBuckets - 1) atomicAdd(&s_hist[tg][b1], 1u);
+                packed |= ((unsigned)b0 | ((unsigned)b1 << 8)) << (16 * h);
             }
             s_pk[m][lane] = packed;
         }
@@ -1099,12 +1155,12 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         // ---- jb = first bucket whose running count reaches k
         {
             int mine = 0;
-            for (int q = 0; q < bpl; ++q) mine += (int)s_hist[sl * bpl + q][tg];
+            for (int q = 0; q < bpl; ++q) mine += (int)s_hist[tg][sl * bpl + q];
             const int incl = group_scan(mine, sl, S);
             int run_count = incl - mine;
             if (run_count < kout && incl >= kout) {
                 for (int q = 0; q < bpl; ++q) {
-                    run_count += (int)s_hist[sl * bpl + q][tg];
+                    run_count += (int)s_hist[tg][sl * bpl + q];
                     if (run_count >= kout) {
                         s_jb[tg] = sl * bpl + q;
                         break;
@@ -1144,7 +1200,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         while (qmask) {
             const int slot = __ffs(qmask) - 1;
             qmask &= qmask - 1u;
-            if (pos < CAP) s_bx[pos][tg] = __float_as_int(tile[ws + sl + slot * S].w);
+            if (pos < CAP)
+                s_bx[tg][pos] = tw_[(wsp + sl + (slot >> 1) * S) * 2 + (slot & 1)];
             ++pos;
         }
         if (sl == 0) s_cnt[tg] = n;
@@ -1167,7 +1224,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             ei[o] = 0x7fffffff;
             rank[o] = 0;
             if (live) {
-                const i64 s = (i64)s_bx[e][tg];
+                const i64 s = (i64)s_bx[tg][e];
                 const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
                 const double2 xy = r2[0], zw = r2[1];
                 const double dx = xy.x - px;
@@ -1178,8 +1235,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                 if (ndim > 2) d2 = d2 + dz * dz;
                 ed[o] = d2;
                 ei[o] = record_id(zw.y);
-                s_bd[e][tg] = d2;
-                s_bx[e][tg] = ei[o];
+                s_bd[tg][e] = d2;
+                s_bx[tg][e] = ei[o];
             }
         }
         wave_sync();
@@ -1189,7 +1246,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         for (int j0 = 0; j0 < nmax; j0 += U) {
             double dj[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[min(j0 + u, CAP - 1)][tg] : INFINITY;
+            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[tg][min(j0 + u, CAP - 1)] : INFINITY;
 #pragma unroll
             for (int o = 0; o < MAXE; ++o) {
                 if (o < owned) {
@@ -1213,8 +1270,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             for (int o = 0; o < MAXE; ++o) rank[o] = 0;
             for (int j = 0; j < nmax; ++j) {
                 const bool live = j < n;
-                const double dj = live ? s_bd[min(j, CAP - 1)][tg] : INFINITY;
-                const int ij = live ? s_bx[min(j, CAP - 1)][tg] : 0x7fffffff;
+                const double dj = live ? s_bd[tg][min(j, CAP - 1)] : INFINITY;
+                const int ij = live ? s_bx[tg][min(j, CAP - 1)] : 0x7fffffff;
 #pragma unroll
                 for (int o = 0; o < MAXE; ++o)
                     if (o < owned) rank[o] += before(dj, ij, ed[o], ei[o]) ? 1 : 0;
@@ -1227,8 +1284,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         for (int o = 0; o < MAXE; ++o) {
             const int e = sl + o * S;
             if (o < owned && e < n && e < CAP) {
-                s_bd[rank[o]][tg] = ed[o];
-                s_bx[rank[o]][tg] = ei[o];
+                s_bd[tg][rank[o]] = ed[o];
+                s_bx[tg][rank[o]] = ei[o];
             }
         }
         wave_sync();
@@ -1238,22 +1295,21 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             double *drow = dist_out ? dist_out + i * kout : nullptr;
             if (sizeof(IDX) == 4 && (kout & 3) == 0) {
                 for (int e = 4 * sl; e < kout; e += 4 * S)
-                    *reinterpret_cast<int4 *>(row + e) =
-                        make_int4(s_bx[e][tg], s_bx[e + 1][tg], s_bx[e + 2][tg], s_bx[e + 3][tg]);
+                    *reinterpret_cast<int4 *>(row + e) = *reinterpret_cast<const int4 *>(&s_bx[tg][e]);
             } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
                 for (int e = 2 * sl; e < kout; e += 2 * S) {
-                    *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_bx[e][tg], (i64)s_bx[e + 1][tg]);
+                    *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_bx[tg][e], (i64)s_bx[tg][e + 1]);
                     if (drow)
-                        *reinterpret_cast<double2 *>(drow + e) = make_double2(sqrt(s_bd[e][tg]), sqrt(s_bd[e + 1][tg]));
+                        *reinterpret_cast<double2 *>(drow + e) = make_double2(sqrt(s_bd[tg][e]), sqrt(s_bd[tg][e + 1]));
                 }
             } else {
                 for (int e = sl; e < kout; e += S) {
-                    row[e] = (IDX)s_bx[e][tg];
-                    if (drow) drow[e] = sqrt(s_bd[e][tg]);
+                    row[e] = (IDX)s_bx[tg][e];
+                    if (drow) drow[e] = sqrt(s_bd[tg][e]);
                 }
             }
             if (sizeof(IDX) == 4 && (kout & 3) == 0 && drow)
-                for (int e = sl; e < kout; e += S) drow[e] = sqrt(s_bd[e][tg]);
+                for (int e = sl; e < kout; e += S) drow[e] = sqrt(s_bd[tg][e]);
         }
         if (dbg_stop == 7) return;
         if (valid && sl == 0) {
@@ -1263,7 +1319,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                 const bool all_y = (cy - 1 <= 0) && (cy + 1 >= g.ny - 1);
                 const bool all_z = (czl - 1 <= 0) && (czl + 1 >= g.nz - 1);
                 if (!(all_x && all_y && all_z)) {
-                    const double kth = s_bd[kout - 1][tg];
+                    const double kth = s_bd[tg][kout - 1];
                     const double bound = block_bound(g, px, py, pz, cx, cy, czl, 1);
                     if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
                 }

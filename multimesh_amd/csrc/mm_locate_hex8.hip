@@ -198,15 +198,44 @@ __device__ __forceinline__ bool in_hull(const double (&xi)[3])
     return !(fabs(xi[0]) > (1 + 1.0)) && !(fabs(xi[1]) > (1 + 1.0)) && !(fabs(xi[2]) > (1 + 1.0));
 }
 
-__device__ __forceinline__ void store_row(i64 *__restrict__ enc, double *__restrict__ w, i64 i,
-                                          const Corners &c, const double (&wt)[8])
+// What happens to a located point.  enc/w non-null: the operator rows are stored (the reference's
+// output).  out non-null: the weighted sum of the element's nodal values is formed right here (A9
+// fused into A4: the fused pipeline then neither writes the 128-byte operator rows nor reads them
+// back in a gather launch).  Same arithmetic as mm_gather for P = 8: every product rounded on its
+// own, summed as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- NumPy's pairwise order for an 8-term row;
+// out-of-range node ids read node 0 like there.
+struct Emit {
+    i64 *enc;
+    double *w;
+    const double *fields;   // [ncomp][nnodes]
+    i64 nnodes;
+    int ncomp;
+    double *out;            // [npoints][ncomp]
+};
+
+__device__ __forceinline__ void emit_row(const Emit &em, i64 i, const i64 (&id)[8], const double (&wt)[8])
 {
-    longlong2 *e2 = reinterpret_cast<longlong2 *>(enc + i * 8);
-    double2 *w2 = reinterpret_cast<double2 *>(w + i * 8);
+    if (em.enc) {
+        longlong2 *e2 = reinterpret_cast<longlong2 *>(em.enc + i * 8);
+        double2 *w2 = reinterpret_cast<double2 *>(em.w + i * 8);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        e2[q] = make_longlong2(c.id[2 * q], c.id[2 * q + 1]);
-        w2[q] = make_double2(wt[2 * q], wt[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) {
+            e2[q] = make_longlong2(id[2 * q], id[2 * q + 1]);
+            w2[q] = make_double2(wt[2 * q], wt[2 * q + 1]);
+        }
+    }
+    if (em.out) {
+        i64 sid[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            sid[n] = (unsigned long long)id[n] < (unsigned long long)em.nnodes ? id[n] : 0;
+        for (int c = 0; c < em.ncomp; ++c) {
+            const double *f = em.fields + (i64)c * em.nnodes;
+            double p[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) p[n] = f[sid[n]] * wt[n];
+            em.out[i * em.ncomp + c] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        }
     }
 }
 
@@ -214,9 +243,8 @@ template <bool EXODUS, typename IDX>
 __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                                                           const IDX *__restrict__ nn,
                                                           const i64 *__restrict__ conn, i64 nelem,
-                                                          i64 *__restrict__ enc,
+                                                          Emit em,
                                                           const double *__restrict__ nodes,
-                                                          double *__restrict__ w,
                                                           const double *__restrict__ pts,
                                                           unsigned long long *__restrict__ nfailed,
                                                           const int *__restrict__ list,
@@ -247,7 +275,7 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                 const double worst = max_abs3(xi);
                 if (worst < (1 + 0.025)) {
                     weights_hex8(xi, wt);
-                    store_row(enc, w, i, c, wt);
+                    emit_row(em, i, c.id, wt);
                     found = true;
                     break;
                 } else if (worst < smallest) {
@@ -262,20 +290,17 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                 load_corners<EXODUS>(conn, nodes, best, c);
                 if (newton_hex8(px, py, pz, c.x, c.y, c.z, xi) && in_hull(xi)) {
                     weights_hex8(xi, wt);
-                    store_row(enc, w, i, c, wt);
+                    emit_row(em, i, c.id, wt);
                     ok = true;
                 }
             }
             failed = !ok;
             if (failed && zero_failed) {
-                // fused pipeline: its private enc/w are not pre-zeroed, failed rows must read as zero
-                longlong2 *e2 = reinterpret_cast<longlong2 *>(enc + i * 8);
-                double2 *w2 = reinterpret_cast<double2 *>(w + i * 8);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e2[q] = make_longlong2(0, 0);
-                    w2[q] = make_double2(0.0, 0.0);
-                }
+                // fused pipeline: its outputs are not pre-zeroed; a failed row reads as zero ids and
+                // zero weights (scripts/cli.py:77-78), and its value is the gather of such a row
+                const i64 zid[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const double zw[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                emit_row(em, i, zid, zw);
             }
         }
     }
@@ -284,26 +309,42 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
     }
 }
 
-constexpr int kPassIters = 10;
+#ifndef MM_PASS_ITERS   // tuning builds only
+#define MM_PASS_ITERS 10
+#endif
+constexpr int kPassIters = MM_PASS_ITERS;
+#ifndef MM_LOCATE_PASSES
+#define MM_LOCATE_PASSES 4
+#endif
 
 // One compacting pass (see "Scheduling" in the header comment).  q_in == null: the open set is
 // every target, starting at candidate 0.
 //
-// Re-queueing.  A single device-scope counter serves only ~88 returning atomics per microsecond
-// (MI355X_MICROARCH.md, "dequeue"), and in the first pass nearly every wave has something to
-// re-queue: one atomic per wave per tile would serialise ~1.8 ms on that word.  So the waves are
-// persistent (grid-stride over tiles) and each wave batches its entries in LDS (slot = ballot
-// prefix, no atomics), reserving queue space with ONE global atomic per ~200 entries and writing
-// them out as coalesced 8-byte stores.
+// Persistent waves with a private retry queue.  Re-queueing every unresolved target through a global
+// queue costs twice: a single device-scope counter serves only ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md, "dequeue"), and -- measured with TCC_MISS -- a later pass over the sparse
+// survivors (a third of the targets after the first solve) misses ~7.6 cache lines per solve against
+// 4.2 in the first pass, because it touches nearly every line of the candidate rows, points and
+// mesh again for a fraction of the work.  So a wave keeps its unresolved targets in LDS and retries
+// them itself as soon as it has a full wave of them; the global queue only carries each wave's
+// last, partial batch (about 1 % of the targets) into a short clean-up pass.
 constexpr int kPassBlock = 256;
-constexpr int kWaveQueue = 256;   // LDS entries per wave; flushed when more than kWaveQueue - 64 are held
+constexpr int kWaveQueue = 128;   // LDS entries per wave (see the append below)
+
+// LDS accesses of one wave are served in program order; only the compiler has to be kept from
+// moving them across the hand-over points of the wave's queue.
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <bool EXODUS, typename IDX>
 __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
-                                                                 i64 *__restrict__ enc,
+                                                                 Emit em,
                                                                  const double *__restrict__ nodes,
-                                                                 double *__restrict__ w,
                                                                  const double *__restrict__ pts,
                                                                  const int2 *__restrict__ q_in,
                                                                  const int *__restrict__ q_in_count,
@@ -315,27 +356,42 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
     __shared__ int2 s_queue[kPassBlock / 64][kWaveQueue];
     const int lane = threadIdx.x & 63;
     int2 *my_queue = s_queue[threadIdx.x >> 6];
-    int held = 0;  // wave-uniform: entries waiting in my_queue
+    int held = 0;  // wave-uniform: unresolved targets waiting in my_queue
 
     const i64 total = q_in ? (i64)*q_in_count : npoints;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const i64 first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    // every lane runs the same number of trips so that the ballots below are wave-wide
-    const i64 trips = (total + stride - 1) / stride;
-    for (i64 trip = 0; trip < trips; ++trip) {
-        const i64 q = first + trip * stride;
-        const bool active = q < total;
+    const i64 nwaves = (i64)gridDim.x * (kPassBlock / 64);
+    const i64 wave = (i64)blockIdx.x * (kPassBlock / 64) + (threadIdx.x >> 6);
+    i64 next = wave * 64;  // first input entry of this wave's next fresh batch
+    for (;;) {
+        // A wave always runs DENSE: as soon as 64 unresolved targets are waiting it retries those on
+        // their next candidate (most recent first: their point, candidate row and mesh lines are
+        // still in cache); otherwise it takes 64 fresh entries.
+        bool active;
         i64 i = 0;
         int j = 0;
-        if (active) {
-            if (q_in) {
-                const int2 e = q_in[q];
-                i = e.x;
-                j = e.y;
-            } else {
-                i = q;
+        if (held >= 64) {
+            held -= 64;
+            const int2 e = my_queue[held + lane];
+            i = e.x;
+            j = e.y;
+            active = true;
+        } else if (next < total) {
+            const i64 q = next + lane;
+            active = q < total;
+            if (active) {
+                if (q_in) {
+                    const int2 e = q_in[q];
+                    i = e.x;
+                    j = e.y;
+                } else {
+                    i = q;
+                }
             }
+            next += nwaves * 64;
+        } else {
+            break;
         }
+        wave_fence();  // the queue reads above happen before this round's appends
         bool requeue = false;
         if (active) {
             const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
@@ -376,7 +432,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 if (converged && in_hull(xi)) {
                     if (max_abs3(xi) < (1 + 0.025)) {
                         weights_hex8(xi, wt);
-                        store_row(enc, w, i, c, wt);
+                        emit_row(em, i, c.id, wt);
                         accepted = true;
                     }
                 }
@@ -386,17 +442,19 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
             }
         }
-        // batch the re-queue entries of this wave in LDS
+        // unresolved targets go to the wave's own queue (slot = ballot prefix, no atomics); fewer than
+        // 64 were waiting and at most 64 are added, so kWaveQueue = 128 entries suffice
         const unsigned long long vote = __ballot(requeue);
         if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j + 1);
         held += __popcll(vote);
-        if (held > kWaveQueue - 64 || (trip == trips - 1 && held > 0)) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(q_out_count, held);
-            base = __shfl(base, 0);
-            for (int t = lane; t < held; t += 64) q_out[base + t] = my_queue[t];
-            held = 0;
-        }
+        wave_fence();
+    }
+    // what is left (fewer than 64 entries) joins the global queue of the next pass: one atomic per wave
+    if (held > 0) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(q_out_count, held);
+        base = __shfl(base, 0);
+        if (lane < held) q_out[base + lane] = my_queue[lane];
     }
 }
 
@@ -417,7 +475,7 @@ __global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restri
 // scratch user between mm_scratch_begin calls of the caller -- it calls mm_scratch_begin itself.
 template <typename IDX>
 static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *nn, const i64 *conn, i64 nelem,
-                               int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
+                               int conn_is_exodus, const Emit &em, const double *nodes, const double *pts,
                                i64 *d_nfailed, int zero_failed)
 {
     MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
@@ -425,7 +483,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     MM_REQUIRE(npoints < (i64)0x7fffffff, "too many targets for one launch");
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
-    constexpr int kPasses = 8;
+    constexpr int kPasses = MM_LOCATE_PASSES;
 
     int rc = mm_scratch_begin(ctx, 2 * mm_round256((size_t)npoints * sizeof(int2)) +
                                        mm_round256((size_t)npoints * sizeof(int)) + 4096);
@@ -440,24 +498,39 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     }
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
+    i64 resident = 0;
+    {
+        int per_cu = 0, cus = 0;
+        hipError_t e = conn_is_exodus
+                           ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX>, kPassBlock, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<false, IDX>, kPassBlock, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        if (e != hipSuccess || per_cu < 1 || cus < 1) {
+            (void)hipGetLastError();
+            per_cu = 2;
+            cus = 256;
+        }
+        resident = (i64)per_cu * cus;
+    }
     for (int p = 0; p < kPasses; ++p) {
         const int2 *q_in = p == 0 ? nullptr : ((p & 1) ? qa : qb);
         int2 *q_out = (p & 1) ? qb : qa;
         const int *q_in_count = p == 0 ? nullptr : counters + p;
         int *q_out_count = counters + p + 1;
-        // persistent waves (see "Re-queueing" above): a bounded grid with a grid-stride loop; later
-        // passes only know their size on the device (the open set shrinks ~3x per pass)
-        i64 grid = full_grid >> (p < 4 ? p : 4);
-        if (grid > 4096) grid = 4096;
-        if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
+        // persistent waves: exactly as many workgroups as the device keeps resident, so that every
+        // wave lives for the whole pass and its private queue sees a long stream of targets.  The
+        // clean-up passes carry ~1 % of the targets and shrink further: fewer, fuller waves.
+        i64 grid = resident >> (2 * p);
+        if (grid < 64) grid = 64;
+        if (grid > full_grid) grid = full_grid;
         dim3 g((unsigned)grid), b(block);
         if (p == 0) mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
         if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
         else
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
         if (p == 0) mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     }
     // whatever is still open after the last pass joins the slow list (reference-order kernel)
@@ -472,26 +545,34 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
         if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+            hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
         else
-            hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, enc,
-                               nodes, w, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+            hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
     }
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }
 
 // nn_is_int32 / zero_failed: the fused pipeline's int32 candidate lists and un-zeroed private
-// enc/w (failed rows are zeroed by the reference-order kernel, the only place a point can fail).
+// outputs (failed rows are zeroed by the reference-order kernel, the only place a point can fail).
+// enc/w may be null when out is given (values only); fields/out null: operator only.
 int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32, const i64 *conn,
                           i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
-                          i64 *d_nfailed, int zero_failed)
+                          i64 *d_nfailed, int zero_failed, const double *fields, i64 nnodes, i64 ncomp, double *out)
 {
+    Emit em;
+    em.enc = (enc && w) ? enc : nullptr;
+    em.w = (enc && w) ? w : nullptr;
+    em.fields = fields;
+    em.nnodes = nnodes;
+    em.ncomp = (int)ncomp;
+    em.out = (fields && out && ncomp > 0) ? out : nullptr;
     if (nn_is_int32)
-        return launch_locate_typed<int>(ctx, k, npoints, (const int *)nn, conn, nelem, conn_is_exodus, enc, nodes, w,
-                                        pts, d_nfailed, zero_failed);
-    return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, enc, nodes, w, pts,
+        return launch_locate_typed<int>(ctx, k, npoints, (const int *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
+                                        d_nfailed, zero_failed);
+    return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
                                     d_nfailed, zero_failed);
 }
 
@@ -508,7 +589,7 @@ extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, c
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
     int rc = mm_launch_locate_hex8(ctx, k, npoints, nn_d, false, (const i64 *)conn_d, nelem, conn_is_exodus,
-                                   (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters, 0);
+                                   (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters, 0, nullptr, 0, 0, nullptr);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) return rc;
     MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost,

@@ -53,13 +53,17 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
 
     rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
     if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn);
-    if (rc == MM_OK && !enc) rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * 8 * sizeof(i64), (void **)&enc);
-    if (rc == MM_OK && !w) rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * 8 * sizeof(double), (void **)&w);
+    // The operator rows are only materialised when the caller asks for them (both pointers): the
+    // interpolated values are formed inside the locate stage, at the point of acceptance.
+    if (!(enc && w)) {
+        enc = nullptr;
+        w = nullptr;
+    }
     if (rc != MM_OK) { result = rc; goto done; }
 
-    // rows of failed points must read as zero (the reference's callers zero-initialise,
+    // rows (and values) of failed points must read as zero (the reference's callers zero-initialise,
     // scripts/cli.py:77-78): the reference-order locate kernel, the only place a point can fail,
-    // zeroes them (no 1.3 GB memset up front)
+    // writes them (no 1.3 GB memset up front)
 
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
     rc = mm_launch_centroid(ctx, 3, nelem, 8, (const i64 *)conn_d, nodes_d, cen);
@@ -76,18 +80,15 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     if (rc != MM_OK) { result = rc; goto done; }
 
+    // locate + gather: scripts/cli.py:86-100.  MM_STAGE_GATHER stays empty on this path (mm_gather is
+    // the stand-alone A9 for callers that keep the operator).
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
     rc = mm_launch_locate_hex8(ctx, k, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
-                               nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1);
+                               nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1,
+                               (out_d && ncomp > 0) ? fields_d : nullptr, nnodes, ncomp, out_d);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) { result = rc; goto done; }
 
-    if (out_d && ncomp > 0) {
-        mm_stage_begin(ctx, MM_STAGE_GATHER);
-        rc = mm_launch_gather(ctx, fields_d, nnodes, ncomp, enc, w, npoints, 8, out_d, 1);
-        mm_stage_end(ctx, MM_STAGE_GATHER);
-        if (rc != MM_OK) { result = rc; goto done; }
-    }
     e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_HIP, hipGetErrorString(e));

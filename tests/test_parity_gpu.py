@@ -197,6 +197,18 @@ def test_fused_pipeline_golden(ctx, golden, name):
     assert np.array_equal(vals.numpy(), d["values"])
 
 
+@pytest.mark.parametrize("name", ["hex8_small", "hex8_hard_k1", "hex8_hard_k3", "hex8_hard_k20"])
+def test_fused_pipeline_values_only_golden(ctx, golden, name):
+    # values-only call: no operator rows are materialised, the weighted sum is formed inside the
+    # locate kernels.  Same bits as NumPy's gather of the reference's rows, failed points (zero
+    # rows) and the last-candidate fallback included -- compared as raw bytes so that a -0.0 counts.
+    d = golden(name)
+    vals, nf = ctx.interpolate_hex8(d["points_a"], d["conn_a"], d["points_b"], d["fields"],
+                                    nelem_to_search=int(d["k"]))
+    assert nf == int(d["nfailed"])
+    assert vals.numpy().tobytes() == np.ascontiguousarray(d["values"]).tobytes()
+
+
 def test_fused_pipeline_structured_ties(ctx, golden):
     # exact kNN ties: candidate order (hence the chosen element on shared faces) is unspecified in
     # the reference; the interpolated values still agree to rounding.  Tolerance: 1e-13 absolute.
