@@ -15,18 +15,20 @@
 // with -ffp-contract=off, so node ids AND weights are bit-identical to the reference.
 //
 // Scheduling.  Walking the candidates in lockstep makes every wave pay for its unluckiest lane
-// in every round (only ~70 % of mesh-node targets are accepted at the nearest centroid, and a
-// diverging Newton runs to the 50-iteration cap).  So the work is done in compacting PASSES: a
-// pass performs at most one Newton solve per still-open target, then re-queues the unresolved
-// targets densely for the next pass.  Before a solve a lane skips candidates whose corner
+// in every round (only ~67 % of mesh-node targets are accepted at the nearest centroid, 1.6 solves
+// per target on average, and a diverging Newton runs to the 50-iteration cap).  So a solve is the
+// unit of scheduling: persistent waves perform ONE Newton solve per lane and round, keep their
+// unresolved targets in a private LDS queue and retry them, densely packed, on their next
+// candidate (locate_pass_kernel below).  Before a solve a lane skips candidates whose corner
 // bounding box (x and y only, widened by 5 %) cannot contain the point: such a candidate can
 // never be ACCEPTED -- acceptance needs max|xi| < 1.025 and converged x/y residuals, and the
 // trilinear image of [-1.025,1.025]^3 stays within 3*0.025*(1.025^2/2) = 3.94 % of the corner
 // extent outside the corner bounding box (z is excluded because the reference never tests the z
-// residual).  Skipping is therefore invisible whenever some candidate is accepted.  A target that
-// runs out of candidates without an acceptance (so the reference's "least outside" fallback or a
-// failure is due), or whose solve needs more than 10 iterations, is handed to the reference-order
-// kernel below, which redoes it from scratch.
+// residual).  Skipping is therefore invisible whenever some candidate is accepted.  A solve that
+// needs more than kPassIters iterations is parked and resumed by a second launch with the
+// reference's cap of 50.  Only a target that runs out of candidates without an acceptance (so the
+// reference's "least outside" fallback or a failure is due) is handed to the reference-order
+// kernel, which redoes it from scratch.
 //
 // HBM-bound by the roofline accounting (568 B/target when the first candidate is accepted:
 // 24 point + 8k candidates + 64 connectivity row + 192 corner coordinates + 128 out), though
@@ -313,9 +315,7 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
 #define MM_PASS_ITERS 10
 #endif
 constexpr int kPassIters = MM_PASS_ITERS;
-#ifndef MM_LOCATE_PASSES
-#define MM_LOCATE_PASSES 4
-#endif
+
 
 // One compacting pass (see "Scheduling" in the header comment).  q_in == null: the open set is
 // every target, starting at candidate 0.
@@ -326,8 +326,10 @@ constexpr int kPassIters = MM_PASS_ITERS;
 // survivors (a third of the targets after the first solve) misses ~7.6 cache lines per solve against
 // 4.2 in the first pass, because it touches nearly every line of the candidate rows, points and
 // mesh again for a fraction of the work.  So a wave keeps its unresolved targets in LDS and retries
-// them itself as soon as it has a full wave of them; the global queue only carries each wave's
-// last, partial batch (about 1 % of the targets) into a short clean-up pass.
+// them itself as soon as it has a full wave of them, and drains the remainder with a few partly
+// filled rounds once its input is exhausted.  Only targets whose current candidate needs more than
+// kPassIters Newton iterations leave the wave: they are parked in a global "long" queue (about 1 %
+// of the targets) for a second launch of the same kernel with the reference's cap of 50.
 constexpr int kPassBlock = 256;
 constexpr int kWaveQueue = 128;   // LDS entries per wave (see the append below)
 
@@ -340,7 +342,7 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool EXODUS, typename IDX>
+template <bool EXODUS, typename IDX, int MAX_IT>
 __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  Emit em,
@@ -348,15 +350,18 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                                                                  const double *__restrict__ pts,
                                                                  const int2 *__restrict__ q_in,
                                                                  const int *__restrict__ q_in_count,
-                                                                 int2 *__restrict__ q_out,
-                                                                 int *__restrict__ q_out_count,
+                                                                 int2 *__restrict__ long_out,
+                                                                 int *__restrict__ long_count,
                                                                  int *__restrict__ slow_list,
                                                                  int *__restrict__ slow_count)
 {
     __shared__ int2 s_queue[kPassBlock / 64][kWaveQueue];
+    __shared__ int2 s_long[kPassBlock / 64][kWaveQueue];
     const int lane = threadIdx.x & 63;
     int2 *my_queue = s_queue[threadIdx.x >> 6];
-    int held = 0;  // wave-uniform: unresolved targets waiting in my_queue
+    int2 *my_long = s_long[threadIdx.x >> 6];
+    int held = 0;       // wave-uniform: unresolved targets waiting in my_queue
+    int held_long = 0;  // wave-uniform: targets whose current candidate needs the long solve
 
     const i64 total = q_in ? (i64)*q_in_count : npoints;
     const i64 nwaves = (i64)gridDim.x * (kPassBlock / 64);
@@ -388,11 +393,21 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
             }
             next += nwaves * 64;
+        } else if (held > 0) {
+            // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...:
+            // a handful of short rounds at the very end of the pass instead of another pass)
+            active = lane < held;
+            if (active) {
+                const int2 e = my_queue[lane];
+                i = e.x;
+                j = e.y;
+            }
+            held = 0;
         } else {
             break;
         }
         wave_fence();  // the queue reads above happen before this round's appends
-        bool requeue = false;
+        bool requeue = false, go_long = false;
         if (active) {
             const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
             Corners c;
@@ -425,10 +440,11 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             } else {
                 double xi[3], wt[8];
                 bool accepted = false;
-                // A solve that has not converged within kPassIters iterations (p99 is 6) would hold
-                // the whole wave for up to 50: such a target is handed to the reference-order kernel
-                // instead, where slow solves only keep each other company.
-                const bool converged = newton_hex8<kPassIters>(px, py, pz, c.x, c.y, c.z, xi);
+                // MAX_IT = kPassIters: a solve that has not converged by then (p99 is 6 iterations) would
+                // hold the whole wave for up to 50; the target is parked, SAME candidate, for the long
+                // pass, where slow solves only keep each other company.  MAX_IT = 50 is that pass: the
+                // reference's own cap, so "not converged" now means the candidate is rejected.
+                const bool converged = newton_hex8<MAX_IT>(px, py, pz, c.x, c.y, c.z, xi);
                 if (converged && in_hull(xi)) {
                     if (max_abs3(xi) < (1 + 0.025)) {
                         weights_hex8(xi, wt);
@@ -437,7 +453,8 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                     }
                 }
                 if (!accepted) {
-                    if (converged && j + 1 < k) requeue = true;
+                    if (!converged && MAX_IT < 50) go_long = true;
+                    else if (j + 1 < k) requeue = true;
                     else slow_list[atomicAdd(slow_count, 1)] = (int)i;
                 }
             }
@@ -447,31 +464,32 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         const unsigned long long vote = __ballot(requeue);
         if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j + 1);
         held += __popcll(vote);
+        if (MAX_IT < 50) {
+            const unsigned long long lvote = __ballot(go_long);
+            if (go_long) my_long[held_long + __popcll(lvote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
+            held_long += __popcll(lvote);
+            if (held_long > kWaveQueue - 64) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(long_count, held_long);
+                base = __shfl(base, 0);
+                for (int t = lane; t < held_long; t += 64) long_out[base + t] = my_long[t];
+                held_long = 0;
+            }
+        }
         wave_fence();
     }
-    // what is left (fewer than 64 entries) joins the global queue of the next pass: one atomic per wave
-    if (held > 0) {
+    if (MAX_IT < 50 && held_long > 0) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(q_out_count, held);
+        if (lane == 0) base = atomicAdd(long_count, held_long);
         base = __shfl(base, 0);
-        if (lane < held) q_out[base + lane] = my_queue[lane];
+        if (lane < held_long) long_out[base + lane] = my_long[lane];
     }
-}
-
-__global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restrict__ q,
-                                                            const int *__restrict__ q_count,
-                                                            int *__restrict__ list, int *__restrict__ list_count)
-{
-    const i64 total = *q_count;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
-        list[atomicAdd(list_count, 1)] = q[t].x;
 }
 
 }  // namespace
 
-// Launch the whole locate stage on ctx->stream (no synchronisation).  Scratch: two pass queues,
-// the slow list and their counters come from the context's scratch pool, so this must be the only
+// Launch the whole locate stage on ctx->stream (no synchronisation).  Scratch: the long queue,
+// the reference-order list and their counters come from the context's scratch pool, so this must be the only
 // scratch user between mm_scratch_begin calls of the caller -- it calls mm_scratch_begin itself.
 template <typename IDX>
 static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *nn, const i64 *conn, i64 nelem,
@@ -483,27 +501,25 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     MM_REQUIRE(npoints < (i64)0x7fffffff, "too many targets for one launch");
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
-    constexpr int kPasses = MM_LOCATE_PASSES;
 
-    int rc = mm_scratch_begin(ctx, 2 * mm_round256((size_t)npoints * sizeof(int2)) +
+    int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int2)) +
                                        mm_round256((size_t)npoints * sizeof(int)) + 4096);
     if (rc != MM_OK) return rc;
-    int2 *qa = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
-    int2 *qb = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    int2 *ql = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));   // input of the long pass
     int *slow = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
-    int *counters = (int *)mm_scratch_take(ctx, 256);  // [0..kPasses]: queue sizes, [15]: slow count
-    if (!qa || !qb || !slow || !counters) {
+    int *counters = (int *)mm_scratch_take(ctx, 256);  // [8] long queue, [15] reference-order list
+    if (!ql || !slow || !counters) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
+    int *long_count = counters + 8;
     i64 resident = 0;
     {
         int per_cu = 0, cus = 0;
-        hipError_t e = conn_is_exodus
-                           ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX>, kPassBlock, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<false, IDX>, kPassBlock, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, kPassIters>,
+                                                                    kPassBlock, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         if (e != hipSuccess || per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
@@ -512,35 +528,37 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         }
         resident = (i64)per_cu * cus;
     }
-    for (int p = 0; p < kPasses; ++p) {
-        const int2 *q_in = p == 0 ? nullptr : ((p & 1) ? qa : qb);
-        int2 *q_out = (p & 1) ? qb : qa;
-        const int *q_in_count = p == 0 ? nullptr : counters + p;
-        int *q_out_count = counters + p + 1;
-        // persistent waves: exactly as many workgroups as the device keeps resident, so that every
-        // wave lives for the whole pass and its private queue sees a long stream of targets.  The
-        // clean-up passes carry ~1 % of the targets and shrink further: fewer, fuller waves.
-        i64 grid = resident >> (2 * p);
-        if (grid < 64) grid = 64;
-        if (grid > full_grid) grid = full_grid;
-        dim3 g((unsigned)grid), b(block);
-        if (p == 0) mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
-        if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
-        else
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, q_in, q_in_count, q_out, q_out_count, slow, slow_count);
-        if (p == 0) mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
-    }
-    // whatever is still open after the last pass joins the slow list (reference-order kernel)
+#define MM_LAUNCH_PASS(MAXIT, GRID, QIN, QIN_COUNT, LONG_OUT)                                                            \
+    do {                                                                                                              \
+        dim3 g_((unsigned)(GRID)), b_(block);                                                                         \
+        if (conn_is_exodus)                                                                                           \
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, MAXIT>), g_, b_, 0, ctx->stream, k, npoints, nn, conn,  \
+                               nelem, em, nodes, pts, QIN, QIN_COUNT, LONG_OUT, long_count, slow, slow_count);        \
+        else                                                                                                          \
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, MAXIT>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, \
+                               nelem, em, nodes, pts, QIN, QIN_COUNT, LONG_OUT, long_count, slow, slow_count);        \
+    } while (0)
+
+    // short pass (Newton capped at kPassIters) over all targets.  Persistent waves: exactly as many
+    // workgroups as the device keeps resident, so that every wave lives for the whole pass and its
+    // private queue sees a long stream of targets.
     {
-        const int2 *q_last = (kPasses & 1) ? qa : qb;
-        const int *q_last_count = counters + kPasses;
-        i64 grid = full_grid >> 4;
-        if (grid < 64) grid = full_grid < 64 ? full_grid : 64;
-        hipLaunchKernelGGL(queue_to_list_kernel, dim3((unsigned)grid), dim3(block), 0, ctx->stream, q_last,
-                           q_last_count, slow, slow_count);
+        i64 grid = resident < full_grid ? resident : full_grid;
+        mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
+        MM_LAUNCH_PASS(kPassIters, grid, nullptr, nullptr, ql);
+        mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
+    }
+    // long pass (the reference's cap of 50 iterations): parked targets resume at the candidate that
+    // was too slow and keep going through their wave's queue like everybody else.  ~1 % of the
+    // targets, and the time goes into 50-iteration chains: as many waves as fit, each takes one
+    // dense batch (waves beyond the queue's length leave at once).
+    {
+        i64 grid = resident < full_grid ? resident : full_grid;
+        MM_LAUNCH_PASS(50, grid, ql, long_count, nullptr);
+    }
+#undef MM_LAUNCH_PASS
+    // targets that ran out of candidates without an acceptance: reference-order kernel
+    {
         i64 sgrid = full_grid >> 3;
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
@@ -552,6 +570,14 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                                nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
     }
     MM_HIP_CHECK(hipGetLastError());
+    if (getenv("MM_LOCATE_DEBUG")) {
+        // diagnostic: sizes of the pass queues and of the reference-order list (synchronises)
+        int h[16];
+        MM_HIP_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[mm_locate] %lld targets; long queue %d; reference-order list %d\n", (long long)npoints, h[8],
+                h[15]);
+    }
     return MM_OK;
 }
 
