@@ -876,6 +876,11 @@ constexpr int kStripZ = MM_STRIP_Z;
 constexpr int kStripLayers = kStripZ + 2;
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kStripTileCap = MM_STRIP_CAP;
+#ifndef MM_STRIP_GROUPS
+#define MM_STRIP_GROUPS 8
+#endif
+constexpr int kStripGroups = MM_STRIP_GROUPS;            // targets per round at the narrowest split
+constexpr int kStripSlots = kTileCap / (kWave / kStripGroups);   // window entries per lane at the narrowest split
 static_assert(kStripLayers * 9 <= kWave, "one lane stages one tile cell");
 
 template <int K, int CAP, typename IDX>
@@ -911,17 +916,17 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     constexpr int kBdStride = CAP | 1;                 // doubles per group (odd)
     constexpr int kBxStride = (CAP + 7) / 4 * 4;       // ints per group (rows stay 16-byte aligned)
     constexpr int kHistStride = kHistBuckets + 1;      // words per group (odd)
-    constexpr int kPkBytes = (kSlots / 4) * kWave * 4, kBdBytes = kMaxGroups * kBdStride * 8;
-    constexpr int kHistBytes = kMaxGroups * kHistStride * 4, kBxBytes = kMaxGroups * kBxStride * 4;
+    constexpr int kPkBytes = (kStripSlots / 4) * kWave * 4, kBdBytes = kStripGroups * kBdStride * 8;
+    constexpr int kHistBytes = kStripGroups * kHistStride * 4, kBxBytes = kStripGroups * kBxStride * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem0[kPkBytes > kBdBytes ? kPkBytes : kBdBytes];
     __shared__ __attribute__((aligned(16))) unsigned char s_mem1[kHistBytes > kBxBytes ? kHistBytes : kBxBytes];
     unsigned (*const s_pk)[kWave] = reinterpret_cast<unsigned (*)[kWave]>(s_mem0);
     double (*const s_bd)[kBdStride] = reinterpret_cast<double (*)[kBdStride]>(s_mem0);
     unsigned (*const s_hist)[kHistStride] = reinterpret_cast<unsigned (*)[kHistStride]>(s_mem1);
     int (*const s_bx)[kBxStride] = reinterpret_cast<int (*)[kBxStride]>(s_mem1);
-    __shared__ int s_jb[kMaxGroups];
-    __shared__ int s_cnt[kMaxGroups];
-    __shared__ unsigned long long s_seen[kMaxGroups];
+    __shared__ int s_jb[kStripGroups];
+    __shared__ int s_cnt[kStripGroups];
+    __shared__ unsigned long long s_seen[kStripGroups];
     __shared__ int s_layer[kStripLayers + 1];
 
     const int lane = threadIdx.x;
@@ -953,7 +958,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     double npx, npy, npz, npw;
     {
         int S1 = kWave;
-        while (S1 > kWave / kMaxGroups && kWave / S1 < tn) S1 >>= 1;
+        while (S1 > kWave / kStripGroups && kWave / S1 < tn) S1 >>= 1;
         const int tg1 = lane / S1;
         const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (tg1 < tn ? tg1 : 0)) * kRec);
         const double2 xy = r2[0], zw = r2[1];
@@ -994,17 +999,20 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (lane < ntc && c == 0) s_layer[layer] = off;
         if (lane == 0) s_layer[nlayers] = total;
         if (total <= kStripTileCap) {
-            for (int q = 0; __any(q < cnt); q += 2) {
-                double2 xy[2], zw[2];
+            // eight records per trip: a cell holds ~8 sources, so most strips need a single trip and
+            // all of its loads are in flight together (the registers are free before the rounds start)
+            constexpr int kCopy = 8;
+            for (int q = 0; __any(q < cnt); q += kCopy) {
+                double2 xy[kCopy], zw[kCopy];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < kCopy; ++u) {
                     const i64 s = (i64)s0 + min(q + u, max(cnt - 1, 0));
                     const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
                     xy[u] = r2[0];
                     zw[u] = r2[1];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < kCopy; ++u)
                     if (q + u < cnt) {
                         const int e = off + q + u;
                         const int at = (e >> 1) * 4 + (e & 1);
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         // lanes per target: the widest split whose round still covers the remaining targets
         const int rem = tn - r0;
         int S = kWave;
-        while (S > kWave / kMaxGroups && kWave / S < rem) S >>= 1;
+        while (S > kWave / kStripGroups && kWave / S < rem) S >>= 1;
         tpw = kWave / S;
         const int tg = lane / S;         // this lane's target slot in the round
         const int sl = lane % S;         // this lane's slice of the window
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             // next round's targets (its split may be wider), in flight during this round
             const int rem2 = rem - tpw;
             int S2 = kWave;
-            while (S2 > kWave / kMaxGroups && kWave / S2 < rem2) S2 >>= 1;
+            while (S2 > kWave / kStripGroups && kWave / S2 < rem2) S2 >>= 1;
             const int tg2 = lane / S2;
             const double2 *r2 =
                 reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + r0 + tpw + (tg2 < rem2 ? tg2 : 0)) * kRec);
@@ -1085,8 +1093,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             npz = zw.x;
             npw = zw.y;
         }
-        for (int q = lane; q < (kHistBuckets + 1) * kMaxGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
-        if (lane < kMaxGroups) {
+        for (int q = lane; q < (kHistBuckets + 1) * kStripGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
+        if (lane < kStripGroups) {
             s_jb[lane] = kHistBuckets;
             s_seen[lane] = 0ull;
         }
@@ -1184,22 +1192,22 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         // ---- P2: candidates in buckets <= jb+1 go to the target's list
         // (four bucket numbers per word, each < 64: adding 126 - jb sets a byte's top bit exactly when
         // its bucket is >= jb + 2, without carries; the multiply gathers the four flags)
-        unsigned qmask = 0u;
+        unsigned long long qmask = 0ull;
         {
             const unsigned bias = (unsigned)(126 - min(jb, kHistBuckets)) * 0x01010101u;
             for (int m = 0; m < nbatch; ++m) {
                 const unsigned keep = (~(s_pk[m][lane] + bias) & 0x80808080u) >> 7;
-                qmask |= (((keep * 0x00204081u) >> 21) & 0xfu) << (m * U);
+                qmask |= (unsigned long long)(((keep * 0x00204081u) >> 21) & 0xfu) << (m * U);
             }
         }
-        if (hand_over) qmask = 0u;
-        const int mycnt = __popc(qmask);
+        if (hand_over) qmask = 0ull;
+        const int mycnt = __popcll(qmask);
         const int incl = group_scan(mycnt, sl, S);
         const int n = __shfl(incl, tg * S + S - 1);
         int pos = incl - mycnt;
         while (qmask) {
-            const int slot = __ffs(qmask) - 1;
-            qmask &= qmask - 1u;
+            const int slot = __ffsll((long long)qmask) - 1;
+            qmask &= qmask - 1ull;
             if (pos < CAP)
                 s_bx[tg][pos] = tw_[(wsp + sl + (slot >> 1) * S) * 2 + (slot & 1)];
             ++pos;
@@ -1213,7 +1221,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         const int owned = (nmax + S - 1) / S;  // list entries per lane: sl, sl+S, ...
 
         // ---- exact fp64 distance (reference arithmetic) and source id of the owned entries
-        constexpr int MAXE = (CAP + 7) / 8;
+        constexpr int MAXE = (CAP + kWave / kStripGroups - 1) / (kWave / kStripGroups);  // at the narrowest split
         double ed[MAXE];
         int ei[MAXE], rank[MAXE];
 #pragma unroll
