@@ -348,17 +348,30 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
                     if (lat2 + ddz * ddz > kth_now) continue;
                     const int s0 = cell_start[col + za];
                     const int s1 = cell_start[col + zb + 1];
-                    for (int s = s0; s < s1; ++s) {
-                        const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)s * kRec);
-                        const double2 xy = r2[0], zw = r2[1];
-                        const double dx = xy.x - px;
-                        const double dy = xy.y - py;
-                        const double dz = zw.x - pz;
-                        double d2 = dx * dx;
-                        d2 = d2 + dy * dy;
-                        if (ndim > 2) d2 = d2 + dz * dz;
-                        const int sid = record_id(zw.y);
-                        if (before(d2, sid, best.d[K - 1], best.id[K - 1])) best.insert(d2, sid);
+                    // four records per trip: their loads are in flight together (this kernel serves few,
+                    // scattered targets and is bound by the latency of its dependent loads)
+                    for (int s = s0; s < s1; s += 4) {
+                        double2 xy[4], zw[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double2 *r2 =
+                                reinterpret_cast<const double2 *>(sorted_xyz + (i64)min(s + u, s1 - 1) * kRec);
+                            xy[u] = r2[0];
+                            zw[u] = r2[1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (s + u < s1) {
+                                const double dx = xy[u].x - px;
+                                const double dy = xy[u].y - py;
+                                const double dz = zw[u].x - pz;
+                                double d2 = dx * dx;
+                                d2 = d2 + dy * dy;
+                                if (ndim > 2) d2 = d2 + dz * dz;
+                                const int sid = record_id(zw[u].y);
+                                if (before(d2, sid, best.d[K - 1], best.id[K - 1])) best.insert(d2, sid);
+                            }
+                        }
                     }
                 }
             }
