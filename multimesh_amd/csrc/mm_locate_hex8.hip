@@ -58,10 +58,9 @@ __device__ __forceinline__ double map_axis(const double (&v)[8], double hr, doub
 
 // Newton inversion (trilinearinterpolator.c:260-305).  x/y/z hold the corner coordinates per
 // axis.  Returns true when converged; xi receives the last iterate either way.
-template <int MAX_IT = 50>
 __device__ __forceinline__ bool newton_hex8(const double px, const double py, const double pz,
                                             const double (&x)[8], const double (&y)[8],
-                                            const double (&z)[8], double (&xi)[3])
+                                            const double (&z)[8], double (&xi)[3], const int max_it = 50)
 {
     xi[0] = 0.;
     xi[1] = 0.;
@@ -72,7 +71,7 @@ __device__ __forceinline__ bool newton_hex8(const double px, const double py, co
     const double sxy = sx > sy ? sx : sy;
     const double scale = sz > sxy ? sz : sxy;
     const double tol = 1e-8 * scale;
-    for (int it = 0; it < MAX_IT; ++it) {
+    for (int it = 0; it < max_it; ++it) {
         const double hr = 0.5 * (xi[0] + 1.0);
         const double hs = 0.5 * (xi[1] + 1.0);
         const double ht = 0.5 * (xi[2] + 1.0);
@@ -342,8 +341,9 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool EXODUS, typename IDX, int MAX_IT>
-__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn,
+template <bool EXODUS, typename IDX>
+__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, i64 k, i64 npoints,
+                                                                 const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  Emit em,
                                                                  const double *__restrict__ nodes,
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         bool active;
         i64 i = 0;
         int j = 0;
+        int cap = kPassIters;  // retries from the wave's queue are ordinary solves
         if (held >= 64) {
             held -= 64;
             const int2 e = my_queue[held + lane];
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
             }
             next += nwaves * 64;
+            cap = fresh_cap;  // a long launch resumes parked solves with the reference's cap
         } else if (held > 0) {
             // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...:
             // a handful of short rounds at the very end of the pass instead of another pass)
@@ -440,11 +442,11 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             } else {
                 double xi[3], wt[8];
                 bool accepted = false;
-                // MAX_IT = kPassIters: a solve that has not converged by then (p99 is 6 iterations) would
-                // hold the whole wave for up to 50; the target is parked, SAME candidate, for the long
-                // pass, where slow solves only keep each other company.  MAX_IT = 50 is that pass: the
-                // reference's own cap, so "not converged" now means the candidate is rejected.
-                const bool converged = newton_hex8<MAX_IT>(px, py, pz, c.x, c.y, c.z, xi);
+                // A solve that has not converged within kPassIters iterations (p99 is 6) would hold the
+                // whole wave for up to 50; the target is parked, SAME candidate, for the next (long)
+                // launch, whose fresh entries run with the reference's own cap of 50 -- there slow solves
+                // only keep each other company, and "not converged" means the candidate is rejected.
+                const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap);
                 if (converged && in_hull(xi)) {
                     if (max_abs3(xi) < (1 + 0.025)) {
                         weights_hex8(xi, wt);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                     }
                 }
                 if (!accepted) {
-                    if (!converged && MAX_IT < 50) go_long = true;
+                    if (!converged && cap < 50) go_long = true;
                     else if (j + 1 < k) requeue = true;
                     else slow_list[atomicAdd(slow_count, 1)] = (int)i;
                 }
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         const unsigned long long vote = __ballot(requeue);
         if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j + 1);
         held += __popcll(vote);
-        if (MAX_IT < 50) {
+        {
             const unsigned long long lvote = __ballot(go_long);
             if (go_long) my_long[held_long + __popcll(lvote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
             held_long += __popcll(lvote);
@@ -478,12 +480,22 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         }
         wave_fence();
     }
-    if (MAX_IT < 50 && held_long > 0) {
+    if (held_long > 0) {
         int base = 0;
         if (lane == 0) base = atomicAdd(long_count, held_long);
         base = __shfl(base, 0);
         if (lane < held_long) long_out[base + lane] = my_long[lane];
     }
+}
+
+__global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restrict__ q,
+                                                            const int *__restrict__ q_count,
+                                                            int *__restrict__ list, int *__restrict__ list_count)
+{
+    const i64 total = *q_count;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
+        list[atomicAdd(list_count, 1)] = q[t].x;
 }
 
 }  // namespace
@@ -502,24 +514,26 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
 
-    int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int2)) +
+    // the parked queues can hold every target in principle (a mesh on which no solve converges quickly)
+    int rc = mm_scratch_begin(ctx, 2 * mm_round256((size_t)npoints * sizeof(int2)) +
                                        mm_round256((size_t)npoints * sizeof(int)) + 4096);
     if (rc != MM_OK) return rc;
-    int2 *ql = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));   // input of the long pass
+    int2 *park[2];
+    park[0] = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    park[1] = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
     int *slow = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
-    int *counters = (int *)mm_scratch_take(ctx, 256);  // [8] long queue, [15] reference-order list
-    if (!ql || !slow || !counters) {
+    int *counters = (int *)mm_scratch_take(ctx, 256);  // [8..8+kLongPasses] parked queues, [15] reference-order list
+    if (!park[0] || !park[1] || !slow || !counters) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
-    int *long_count = counters + 8;
+    constexpr int kLongPasses = 3;
     i64 resident = 0;
     {
         int per_cu = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, kPassIters>,
-                                                                    kPassBlock, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX>, kPassBlock, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         if (e != hipSuccess || per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
@@ -528,37 +542,34 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         }
         resident = (i64)per_cu * cus;
     }
-#define MM_LAUNCH_PASS(MAXIT, GRID, QIN, QIN_COUNT, LONG_OUT)                                                            \
-    do {                                                                                                              \
-        dim3 g_((unsigned)(GRID)), b_(block);                                                                         \
-        if (conn_is_exodus)                                                                                           \
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, MAXIT>), g_, b_, 0, ctx->stream, k, npoints, nn, conn,  \
-                               nelem, em, nodes, pts, QIN, QIN_COUNT, LONG_OUT, long_count, slow, slow_count);        \
-        else                                                                                                          \
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, MAXIT>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, \
-                               nelem, em, nodes, pts, QIN, QIN_COUNT, LONG_OUT, long_count, slow, slow_count);        \
+    const i64 grid = resident < full_grid ? resident : full_grid;
+#define MM_LAUNCH_PASS(FRESH_CAP, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT)                                                 \
+    do {                                                                                                             \
+        dim3 g_((unsigned)grid), b_(block);                                                                          \
+        if (conn_is_exodus)                                                                                          \
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g_, b_, 0, ctx->stream, FRESH_CAP, k, npoints, nn,   \
+                               conn, nelem, em, nodes, pts, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT, slow, slow_count); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g_, b_, 0, ctx->stream, FRESH_CAP, k, npoints, nn,  \
+                               conn, nelem, em, nodes, pts, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT, slow, slow_count); \
     } while (0)
 
-    // short pass (Newton capped at kPassIters) over all targets.  Persistent waves: exactly as many
-    // workgroups as the device keeps resident, so that every wave lives for the whole pass and its
-    // private queue sees a long stream of targets.
-    {
-        i64 grid = resident < full_grid ? resident : full_grid;
-        mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
-        MM_LAUNCH_PASS(kPassIters, grid, nullptr, nullptr, ql);
-        mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
-    }
-    // long pass (the reference's cap of 50 iterations): parked targets resume at the candidate that
-    // was too slow and keep going through their wave's queue like everybody else.  ~1 % of the
-    // targets, and the time goes into 50-iteration chains: as many waves as fit, each takes one
-    // dense batch (waves beyond the queue's length leave at once).
-    {
-        i64 grid = resident < full_grid ? resident : full_grid;
-        MM_LAUNCH_PASS(50, grid, ql, long_count, nullptr);
-    }
+    // short launch (every Newton solve capped at kPassIters) over all targets.  Persistent waves:
+    // exactly as many workgroups as the device keeps resident, so that every wave lives for the whole
+    // pass and its private queue sees a long stream of targets.
+    mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
+    MM_LAUNCH_PASS(kPassIters, nullptr, nullptr, park[0], counters + 8);
+    mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
+    // long launches: the parked solves (~1 % of the targets) resume with the reference's cap of 50
+    // iterations; what follows for those targets is ordinary again (short solves from the wave's
+    // queue, parking anew what is slow).  Waves beyond a queue's length leave at once.
+    for (int p = 0; p < kLongPasses; ++p)
+        MM_LAUNCH_PASS(50, park[p & 1], counters + 8 + p, park[(p + 1) & 1], counters + 9 + p);
 #undef MM_LAUNCH_PASS
-    // targets that ran out of candidates without an acceptance: reference-order kernel
+    // still parked after that, or out of candidates without an acceptance: reference-order kernel
     {
+        hipLaunchKernelGGL(queue_to_list_kernel, dim3(64), dim3(block), 0, ctx->stream, park[kLongPasses & 1],
+                           counters + 8 + kLongPasses, slow, slow_count);
         i64 sgrid = full_grid >> 3;
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
@@ -575,8 +586,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         int h[16];
         MM_HIP_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[mm_locate] %lld targets; long queue %d; reference-order list %d\n", (long long)npoints, h[8],
-                h[15]);
+        fprintf(stderr, "[mm_locate] %lld targets; parked after each launch: %d %d %d %d; reference-order list %d\n",
+                (long long)npoints, h[8], h[9], h[10], h[11], h[15]);
     }
     return MM_OK;
 }
