@@ -53,7 +53,7 @@ def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
 
 #: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
-KERNEL_OF_STAGE = {"centroid": "centroid_kernel<3, 8>", "knn_cell": "knn_strip_kernel<20, 32, int>",
+KERNEL_OF_STAGE = {"centroid": "centroid_kernel<3, 8>", "knn_cell": "knn_strip_kernel<8, 20, int>",
                    "locate_pass0": "locate_pass_kernel<true, int> (first pass)", "gather": "gather8_kernel<true>"}
 
 
@@ -237,6 +237,9 @@ def main():
             "config": {"workload": f"hex8 3D {n_nodes}->{n_local} nodes per GPU (n_src={n_src}, n_tgt={n_tgt} per side, "
                                    f"jittered unit cube), {ncomp} field component(s), k={k}",
                        "source_nodes": n_nodes, "source_elements": n_elem, "targets_per_gpu": n_local,
+                       "candidate_lists": "evaluated lazily: the 8 nearest centroids up front, the full "
+                                          f"k={k} list only for targets that exhaust them; every output is "
+                                          "bit-identical to the eager evaluation (mm_set_lazy_lists(0))",
                        "parallelism": f"targets sharded x{world}, source replicated, 1 all-gather" if world > 1
                        else "single GPU"},
             "nfailed": nfailed_total,

@@ -154,6 +154,14 @@ int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnod
                             int64_t npoints, const double *fields_d, int64_t ncomp,
                             int64_t nelem_to_search, double *out_d, int64_t *enc_d, double *w_d);
 
+/* mm_interpolate_hex8 evaluates its candidate lists lazily (default on): the locate stage walks a
+ * target's candidates in kNN order and stops at the first acceptance (1.6 candidates per target on
+ * mesh-like inputs), so the pipeline first asks the kNN stage for the 8 nearest only and computes
+ * the full nelem_to_search list just for the targets that exhaust those 8 (they then go through
+ * the reference-order locate from candidate 0).  The k' nearest are the first k' of the k nearest,
+ * so every output is bit-identical to the eager evaluation; on = 0 forces the eager one. */
+int mm_set_lazy_lists(mm_context *ctx, int on);
+
 /* Stage timers (hipEvents on the context's stream).  With profiling on, every kernel
  * launched by the calls above is bracketed by events; mm_last_timings fills ms[stage] for
  * the stages of the LAST call (0 for stages that did not run) and returns the stage count. */
@@ -161,7 +169,7 @@ enum mm_stage {
     MM_STAGE_CENTROID = 0,
     MM_STAGE_KNN_BUILD = 1,
     MM_STAGE_KNN_QUERY = 2,    /* whole query: target sort + cell kernel + straggler kernel */
-    MM_STAGE_LOCATE = 3,       /* whole locate: all passes + reference-order kernel */
+    MM_STAGE_LOCATE = 3,       /* whole locate: all launches + reference-order kernel (+ on-demand full lists) */
     MM_STAGE_GATHER = 4,
     MM_STAGE_KNN_CELL = 5,     /* the kNN cell kernel alone (inside MM_STAGE_KNN_QUERY) */
     MM_STAGE_LOCATE_PASS0 = 6, /* the first locate pass alone (inside MM_STAGE_LOCATE) */

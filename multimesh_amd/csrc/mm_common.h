@@ -46,6 +46,7 @@ enum mm_buffer_slot {
     MM_BUF_W,
     MM_BUF_CELL_START,
     MM_BUF_SORTED_XYZ,
+    MM_BUF_NN_FULL,
     MM_BUF_COUNT
 };
 
@@ -60,6 +61,7 @@ struct mm_context {
     i64 *h_counters = nullptr;
     // stage timers
     int profiling = 0;
+    int lazy_lists = 1;   // mm_set_lazy_lists
     hipEvent_t ev_begin[MM_STAGE_COUNT];
     hipEvent_t ev_end[MM_STAGE_COUNT];
     bool ev_used[MM_STAGE_COUNT];
@@ -85,10 +87,23 @@ int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64
                        const double *points, double *out);
 // enc/w: operator rows (may be null when out is given); fields [ncomp][nnodes] + out [npoints][ncomp]:
 // interpolated values formed at the acceptance point (the gather fused into the locate), or null
+// lazy (nullable): nn holds only the k nearest of k_full; targets that exhaust them get their full
+// list from the index (written to nn_full int32[npoints][k_full], rows of those targets only) and
+// go through the reference-order kernel
+struct mm_knn_index;
+struct mm_lazy_lists {
+    const mm_knn_index *index;
+    i64 k_full;
+    int *nn_full;
+};
 int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32,
                           const i64 *conn, i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes,
                           double *w, const double *pts, i64 *d_nfailed, int zero_failed,
-                          const double *fields, i64 nnodes, i64 ncomp, double *out);
+                          const double *fields, i64 nnodes, i64 ncomp, double *out,
+                          const mm_lazy_lists *lazy);
+// full-length int32 lists for a device-side list of targets (generic kernel, rows idx[i*k ...])
+int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,
+                           int *idx_d, const int *list, const int *list_count);
 int mm_launch_gather(mm_context *ctx, const double *fields, i64 nsrc, i64 ncomp, const i64 *ids,
                      const double *w, i64 npoints, i64 P, double *out, int out_point_major);
 

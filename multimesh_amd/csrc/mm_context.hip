@@ -211,6 +211,13 @@ extern "C" int mm_set_profiling(mm_context *ctx, int on)
     return MM_OK;
 }
 
+extern "C" int mm_set_lazy_lists(mm_context *ctx, int on)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    ctx->lazy_lists = on ? 1 : 0;
+    return MM_OK;
+}
+
 void mm_stage_reset(mm_context *ctx)
 {
     for (int s = 0; s < MM_STAGE_COUNT; ++s) ctx->ev_used[s] = false;

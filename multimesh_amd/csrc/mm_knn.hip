@@ -1639,6 +1639,22 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     return MM_OK;
 }
 
+int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,
+                           int *idx_d, const int *list, const int *list_count)
+{
+    if (npts == 0 || k == 0) return MM_OK;
+    const GridParams g = params_of(ix);
+    const int kout = (int)k;
+    if (k <= 8) launch_generic<8, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    else if (k <= 16) launch_generic<16, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    else if (k <= 20) launch_generic<20, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    else if (k <= 32) launch_generic<32, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    else if (k <= 40) launch_generic<40, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    else launch_generic<MM_KNN_MAX_K, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
 // idx_is_int32: the fused pipeline keeps its candidate lists as int32 (half the bytes); the public
 // mm_knn_query writes int64 like cKDTree.
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,

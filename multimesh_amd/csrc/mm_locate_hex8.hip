@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restri
 template <typename IDX>
 static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *nn, const i64 *conn, i64 nelem,
                                int conn_is_exodus, const Emit &em, const double *nodes, const double *pts,
-                               i64 *d_nfailed, int zero_failed)
+                               i64 *d_nfailed, int zero_failed, const mm_lazy_lists *lazy)
 {
     MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
     if (npoints == 0 || k == 0) return MM_OK;
@@ -570,15 +570,26 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     {
         hipLaunchKernelGGL(queue_to_list_kernel, dim3(64), dim3(block), 0, ctx->stream, park[kLongPasses & 1],
                            counters + 8 + kLongPasses, slow, slow_count);
+        // lazily evaluated lists: these targets have only seen the nearest k of k_full candidates --
+        // fetch their full lists now; the reference-order kernel starts again at candidate 0 anyway
+        i64 k_slow = k;
+        const IDX *nn_slow = nn;
+        if (lazy && sizeof(IDX) == sizeof(int)) {
+            int lrc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, lazy->k_full, lazy->nn_full, slow,
+                                             slow_count);
+            if (lrc != MM_OK) return lrc;
+            k_slow = lazy->k_full;
+            nn_slow = reinterpret_cast<const IDX *>(lazy->nn_full);
+        }
         i64 sgrid = full_grid >> 3;
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
         if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+            hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
+                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
         else
-            hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+            hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
+                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
     }
     MM_HIP_CHECK(hipGetLastError());
     if (getenv("MM_LOCATE_DEBUG")) {
@@ -597,7 +608,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
 // enc/w may be null when out is given (values only); fields/out null: operator only.
 int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32, const i64 *conn,
                           i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
-                          i64 *d_nfailed, int zero_failed, const double *fields, i64 nnodes, i64 ncomp, double *out)
+                          i64 *d_nfailed, int zero_failed, const double *fields, i64 nnodes, i64 ncomp, double *out,
+                          const mm_lazy_lists *lazy)
 {
     Emit em;
     em.enc = (enc && w) ? enc : nullptr;
@@ -608,9 +620,9 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
     em.out = (fields && out && ncomp > 0) ? out : nullptr;
     if (nn_is_int32)
         return launch_locate_typed<int>(ctx, k, npoints, (const int *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
-                                        d_nfailed, zero_failed);
+                                        d_nfailed, zero_failed, lazy);
     return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
-                                    d_nfailed, zero_failed);
+                                    d_nfailed, zero_failed, nullptr);
 }
 
 extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, const int64_t *nn_d,
@@ -626,7 +638,7 @@ extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, c
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
     int rc = mm_launch_locate_hex8(ctx, k, npoints, nn_d, false, (const i64 *)conn_d, nelem, conn_is_exodus,
-                                   (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters, 0, nullptr, 0, 0, nullptr);
+                                   (i64 *)enc_d, nodes_d, w_d, pts_d, ctx->d_counters, 0, nullptr, 0, 0, nullptr, nullptr);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) return rc;
     MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost,

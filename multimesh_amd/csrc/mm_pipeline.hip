@@ -11,6 +11,10 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
                       double *dist_d, bool idx_is_int32);
 void mm_clear_status(void);
 
+// candidates delivered up front when the lists are evaluated lazily (99.9 % of mesh-node targets are
+// resolved within them; see mm_set_lazy_lists)
+static const int64_t kLazyK = 8;
+
 // -----------------------------------------------------------------------------------------
 // Fused pipeline: centroid -> grid build -> kNN -> locate -> gather.
 // Intermediates (centroids, candidate lists, and the operator when the caller does not ask for
@@ -51,8 +55,15 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
         goto done;                                                     \
     } while (0)
 
+    // lazily evaluated candidate lists (mm_set_lazy_lists): the kNN stage delivers the kq nearest, the
+    // full k only on demand inside the locate stage
+    const int64_t kq = (ctx->lazy_lists && k > kLazyK) ? kLazyK : k;
+    int *nn_full = nullptr;
+    mm_lazy_lists lazy;
     rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
-    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn);
+    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)kq * sizeof(int), (void **)&nn);
+    if (rc == MM_OK && kq < k)
+        rc = mm_buffer_get(ctx, MM_BUF_NN_FULL, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn_full);
     // The operator rows are only materialised when the caller asks for them (both pointers): the
     // interpolated values are formed inside the locate stage, at the point of acceptance.
     if (!(enc && w)) {
@@ -76,16 +87,20 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
-    rc = mm_knn_query_impl(ctx, index, points_d, npoints, k, nn, nullptr, true);
+    rc = mm_knn_query_impl(ctx, index, points_d, npoints, kq, nn, nullptr, true);
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     if (rc != MM_OK) { result = rc; goto done; }
 
     // locate + gather: scripts/cli.py:86-100.  MM_STAGE_GATHER stays empty on this path (mm_gather is
     // the stand-alone A9 for callers that keep the operator).
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
-    rc = mm_launch_locate_hex8(ctx, k, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
+    lazy.index = index;
+    lazy.k_full = k;
+    lazy.nn_full = nn_full;
+    rc = mm_launch_locate_hex8(ctx, kq, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
                                nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1,
-                               (out_d && ncomp > 0) ? fields_d : nullptr, nnodes, ncomp, out_d);
+                               (out_d && ncomp > 0) ? fields_d : nullptr, nnodes, ncomp, out_d,
+                               kq < k ? &lazy : nullptr);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) { result = rc; goto done; }
 

@@ -157,6 +157,11 @@ class Context:
     def set_profiling(self, on=True):
         check(self.lib.mm_set_profiling(self.handle, 1 if on else 0), "mm_set_profiling")
 
+    def set_lazy_lists(self, on=True):
+        """interpolate_hex8 asks the kNN stage for the 8 nearest first and for the full list only for
+        targets that exhaust them (bit-identical outputs; default on)."""
+        check(self.lib.mm_set_lazy_lists(self.handle, 1 if on else 0), "mm_set_lazy_lists")
+
     def last_timings(self):
         """Per-stage milliseconds of the last call (hipEvents on this context's stream)."""
         buf = (C.c_double * len(STAGES))()

@@ -209,6 +209,52 @@ def test_fused_pipeline_values_only_golden(ctx, golden, name):
     assert vals.numpy().tobytes() == np.ascontiguousarray(d["values"]).tobytes()
 
 
+@pytest.mark.parametrize("name", ["hex8_hard_k20", "hex8_small"])
+def test_fused_pipeline_eager_lists_golden(ctx, golden, name):
+    # the same fixtures with the lazy evaluation of the candidate lists switched off (the default,
+    # lazy, is what every other fused test runs): all nelem_to_search candidates up front
+    d = golden(name)
+    ctx.set_lazy_lists(False)
+    try:
+        vals, enc, w, nf = ctx.interpolate_hex8(d["points_a"], d["conn_a"], d["points_b"], d["fields"],
+                                                nelem_to_search=int(d["k"]), want_operator=True)
+    finally:
+        ctx.set_lazy_lists(True)
+    assert nf == int(d["nfailed"])
+    assert np.array_equal(enc.numpy(), d["enc"]) and np.array_equal(w.numpy(), d["w"])
+    assert vals.numpy().tobytes() == np.ascontiguousarray(d["values"]).tobytes()
+
+
+def test_fused_pipeline_lazy_equals_eager_when_lists_run_out(ctx):
+    # a strongly sheared source mesh and targets partly outside it: many targets are not accepted
+    # within their 8 nearest centroids (some in none of 20), so the on-demand full lists, the
+    # reference-order fallback and the failure path all run.  Lazy and eager must agree bit for bit,
+    # and both with the oracle.
+    pa, ca = synth.hex_mesh(24, seed=5, jitter=0.3)
+    pa = pa.copy()
+    pa[:, 0] += 0.9 * pa[:, 2] + 0.5 * pa[:, 1]            # shear: nearest centroid != containing element
+    pa[:, 2] *= 0.15                                       # flat elements
+    rng = np.random.default_rng(11)
+    pb = rng.uniform(pa.min(axis=0) - 0.02, pa.max(axis=0) + 0.02, size=(40_000, 3))
+    fields = synth.vector_field(pa)[:2]
+    out = {}
+    for lazy in (True, False):
+        ctx.set_lazy_lists(lazy)
+        try:
+            vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+        finally:
+            ctx.set_lazy_lists(True)
+        out[lazy] = (vals.numpy(), enc.numpy(), w.numpy(), nf)
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a, b)
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    enc_o, w_o, nf_o, status = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb, want_status=True)
+    assert (status >= 8).sum() > 100                        # candidates beyond the 8th were really needed
+    assert out[True][3] == nf_o and nf_o > 0
+    ok = status >= 0
+    assert np.array_equal(out[True][1][ok], enc_o[ok]) and np.array_equal(out[True][2][ok], w_o[ok])
+
+
 def test_fused_pipeline_structured_ties(ctx, golden):
     # exact kNN ties: candidate order (hence the chosen element on shared faces) is unspecified in
     # the reference; the interpolated values still agree to rounding.  Tolerance: 1e-13 absolute.
