@@ -1382,7 +1382,11 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
                  int kout, const int *tstart, const double *tsorted, IDX *idx, double *dist,
                  int *fb_list, int *fb_count)
 {
-    constexpr int CAP = K + 12;
+#ifndef MM_KNN_CAP_EXTRA_SMALL   // tuning builds only
+#define MM_KNN_CAP_EXTRA_SMALL 8
+#endif
+    // room for the candidates of buckets jb and jb+1 beyond the k-th (fewer for short lists)
+    constexpr int CAP = K + (K <= 8 ? MM_KNN_CAP_EXTRA_SMALL : 12);
     static const int dbg_stop = getenv("MM_KNN_DBG_STOP") ? atoi(getenv("MM_KNN_DBG_STOP")) : 0;
     // 8 XCD slabs of ceil(columns/8) cell columns each (see the kernel's workgroup map)
     const i64 cols = (i64)ix->dims[0] * ix->dims[1];
