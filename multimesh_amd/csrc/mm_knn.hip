@@ -110,17 +110,36 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__rest
                                                             int *__restrict__ counts)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nsrc) return;
-    const double x = src[e * ndim];
-    const double y = ndim > 1 ? src[e * ndim + 1] : 0.0;
-    const double z = ndim > 2 ? src[e * ndim + 2] : 0.0;
-    const int cx = cell_coord(x, g.lox, g.ihx, g.nx);
-    const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
-    const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
-    const int c = (cx * g.ny + cy) * g.nz + cz;
-    // the histogram atomic also hands out the item's rank inside its cell, so the scatter pass
-    // needs no second atomic
-    cell_of[e] = make_int2(c, atomicAdd(&counts[c], 1));
+    const bool live = e < nsrc;
+    int c = -1;
+    if (live) {
+        const double x = src[e * ndim];
+        const double y = ndim > 1 ? src[e * ndim + 1] : 0.0;
+        const double z = ndim > 2 ? src[e * ndim + 2] : 0.0;
+        const int cx = cell_coord(x, g.lox, g.ihx, g.nx);
+        const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
+        const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
+        c = (cx * g.ny + cy) * g.nz + cz;
+    }
+    // The histogram atomic also hands out the item's rank inside its cell, so the scatter pass needs
+    // no second atomic.  Mesh-ordered points arrive in runs of equal cells (neighbours along the
+    // fastest axis), and same-address atomics serialise in L2: the first lane of each run of equal
+    // cells inside the wave adds the run's length, the others take consecutive ranks behind it.
+    // (Random-order input: every run has length 1, nothing lost but a dozen instructions.)
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
+    const int head_lane = 63 - __clzll((long long)upto);
+    const unsigned long long after = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+    int base = 0;
+    if (head && live) {
+        const int next_head = after ? __ffsll((long long)after) - 1 : 64;
+        base = atomicAdd(&counts[c], next_head - lane);
+    }
+    base = __shfl(base, head_lane);
+    if (live) cell_of[e] = make_int2(c, base + (lane - head_lane));
 }
 
 // ---- exclusive scan of the per-cell counts (three small kernels) --------------------
