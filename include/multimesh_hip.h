@@ -144,6 +144,16 @@ int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64
                    const int64_t *elem_d, const double *coeffs_d, int64_t npoints, int64_t P, double *out_d,
                    int out_point_major);
 
+/* Unique points and the index array that rebuilds the input: np.unique(points, axis=0,
+ * return_inverse=True) of reference utils.py:484-488 (get_unique_points, the pre-step of the GLL
+ * target flows; scatter-back at components/interpolator.py:823).  points_d f64[npoints][dim];
+ * unique_d f64[npoints][dim] (room for the worst case), rows in lexicographic (x, y, z) order;
+ * inverse_d int64[npoints] with unique[inverse[i]] == points[i].  -0.0 equals +0.0 as in NumPy (the
+ * row kept is the one with the smallest index); NaN coordinates are not supported.
+ * Returns the number of unique rows, or a negative MM_ERR_*. */
+int64_t mm_unique_points(mm_context *ctx, const double *points_d, int64_t npoints, int64_t dim,
+                         double *unique_d, int64_t *inverse_d);
+
 /* The whole hot path of reference scripts/cli.py:62-100 on resident arrays:
  * centroid -> search grid -> kNN -> locate -> gather.  connectivity_d is the mesh's own
  * (exodus-order) hex8 connectivity.  enc_d / w_d (nullable) receive the interpolation

@@ -203,6 +203,36 @@ def interpolate_gll_to_points(mesh: GllMesh, points, params_to_interp, nelem_to_
     return ctx.gather_elem(fields, elem, coeffs).numpy()
 
 
+def get_unique_points(points, context=None):
+    """Array form of the reference's ``utils.get_unique_points`` (utils.py:484-488):
+    ``np.unique(points.reshape(-1, dim), axis=0, return_inverse=True)`` on the device.
+    ``points`` f64[E, P, dim] (element-nodal) or f64[N, dim] -> (unique f64[U, dim], inverse int64[N])."""
+    ctx = context or default_context()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    uniq, inv = ctx.unique_points(pts.reshape(-1, pts.shape[-1]))
+    return uniq.numpy(), inv.numpy()
+
+
+def interpolate_gll_to_gll(mesh_a: GllMesh, target_gll_points, params_to_interp, nelem_to_search=20,
+                           tolerance=1.05, context=None):
+    """The array core of ``gll_2_gll`` (reference interpolator.py:700-830): the target mesh's
+    element-nodal points are reduced to their unique set (shared faces/edges/corners repeat),
+    interpolated once each, and scattered back with the inverse index (``values[recon]``,
+    interpolator.py:823).  ``target_gll_points`` f64[E_t, P_t, dim] -> f64[C, E_t, P_t]."""
+    ctx = context or default_context()
+    tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
+    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]))
+    tree = ctx.knn_build(mesh_a.get_element_centroid())
+    nn = tree.query(uniq, nelem_to_search)
+    elem, coeffs, num_failed = ctx.locate_gll(mesh_a.shape_order, nn, mesh_a.gll_points, uniq, tolerance, False)
+    if num_failed > 0:
+        print(num_failed, "points could not find an enclosing element. These points will be set to zero. "
+                          "Please check your domain or the interpolation tuning parameters")
+    fields = np.stack([mesh_a.element_nodal_fields[p] for p in params_to_interp])
+    vals = ctx.gather_elem(fields, elem, coeffs).numpy()            # [U, C]
+    return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(params_to_interp), tgt.shape[0], tgt.shape[1])
+
+
 def _gll(name, row):
     def f(*args, **kwargs):
         raise NotImplementedError(f"{name}: the GLL (salvus.fem backed) path is SURVEY.md §8 row {row}; "
@@ -212,7 +242,7 @@ def _gll(name, row):
 
 
 exodus_2_gll = _gll("exodus_2_gll", "A10 / §8f-2")
-gll_2_gll = _gll("gll_2_gll", "A10")
+gll_2_gll = _gll("gll_2_gll", "A10 -- array core: interpolate_gll_to_gll; file I/O is §8f-2")
 gll_2_gll_layered = _gll("gll_2_gll_layered", "A10 / §8f-4")
 gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "A10 / §8f-4")
 gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "A10 / §8f-4")

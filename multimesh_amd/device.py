@@ -289,6 +289,18 @@ class Context:
             return out, enc, w, int(nf)
         return out, int(nf)
 
+    # ---- A11 ----------------------------------------------------------------------------
+    def unique_points(self, points):
+        """``np.unique(points, axis=0, return_inverse=True)`` (reference utils.py:484-488) on the
+        device: (unique f64[U, dim] in lexicographic order, inverse int64[N])."""
+        pts = self.asdevice(points, np.float64)
+        n, dim = pts.shape
+        uniq = self.empty((max(n, 1), dim), np.float64)
+        inv = self.empty((max(n, 1),), np.int64)
+        nu = check(self.lib.mm_unique_points(self.handle, pts.ptr, n, dim, uniq.ptr, inv.ptr), "mm_unique_points")
+        return (DeviceArray(self, uniq.ptr, (int(nu), dim), np.float64, owner=False, keepalive=uniq),
+                DeviceArray(self, inv.ptr, (n,), np.int64, owner=False, keepalive=inv))
+
     def close(self):
         if self.handle:
             self.lib.mm_context_destroy(self.handle)

@@ -114,3 +114,56 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
     assert nf == 0
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"v{r}.npy"), single)        # partition independent
+
+
+# ------------------------------------------------------------------------------- A11
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_unique_points_equal_numpy(dim):
+    # element-nodal GLL points: shared faces / edges / corners repeat (reference utils.py:484-488)
+    from multimesh_amd.device import Context
+    from multimesh_amd import synth
+    pts = synth.gll_mesh(9 if dim == 3 else 40, 4, seed=3, dim=dim).reshape(-1, dim)
+    rng = np.random.default_rng(0)
+    pts = pts[rng.permutation(len(pts))]                    # arbitrary input order
+    pts[::97, 0] = 0.0
+    pts[::194, 0] = -0.0                                    # -0.0 == 0.0 like NumPy
+    ctx = Context(0)
+    uniq, inv = ctx.unique_points(pts)
+    uniq, inv = uniq.numpy(), inv.numpy()
+    ref_u, ref_inv = np.unique(pts, axis=0, return_inverse=True)
+    assert uniq.shape == ref_u.shape and len(ref_u) < len(pts)
+    assert np.array_equal(uniq, ref_u)                      # == : the sign of a zero is not compared
+    assert np.array_equal(inv, ref_inv.reshape(-1))
+    assert np.array_equal(uniq[inv], pts)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_unique_points_edge_cases():
+    from multimesh_amd.device import Context
+    ctx = Context(0)
+    one = np.array([[1.0, 2.0, 3.0]])
+    u, inv = ctx.unique_points(one)
+    assert np.array_equal(u.numpy(), one) and inv.numpy().tolist() == [0]
+    same = np.tile(one, (1000, 1))
+    u, inv = ctx.unique_points(same)
+    assert u.numpy().shape == (1, 3) and not inv.numpy().any()
+    neg = np.array([[-1.0, 5.0], [-2.0, 7.0], [-1.0, -5.0], [3.0, 0.0], [-2.0, 7.0]])
+    u, inv = ctx.unique_points(neg)
+    ref_u, ref_inv = np.unique(neg, axis=0, return_inverse=True)
+    assert np.array_equal(u.numpy(), ref_u) and np.array_equal(inv.numpy(), ref_inv.reshape(-1))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gll_to_gll_on_arrays_reproduces_a_polynomial():
+    # gll_2_gll's array core: unique targets, GLL locate + gather, scatter back with the inverse index
+    from multimesh_amd import api, synth
+    src = synth.gll_mesh(7, 4, seed=1, dim=3)
+    tgt = synth.gll_mesh(6, 4, seed=7, dim=3)
+    poly = lambda p: 1.0 + 2.0 * p[..., 0] - 3.0 * p[..., 1] * p[..., 2] + p[..., 0] ** 2
+    mesh = api.GllMesh(src, 4, {"f": poly(src)})
+    out = api.interpolate_gll_to_gll(mesh, tgt, ["f"])
+    assert out.shape == (1,) + tgt.shape[:2]
+    assert np.abs(out[0] - poly(tgt)).max() < 1e-9          # inside the order-4 space: exact to rounding

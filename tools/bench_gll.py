@@ -18,6 +18,10 @@ tgt_en = synth.gll_mesh(a.n_tgt, a.order, seed=7).reshape(-1, 3)
 t0 = time.time(); tgt = np.unique(tgt_en, axis=0); t_unique = time.time() - t0
 fields = synth.field_smooth(src.reshape(-1, 3)).reshape(1, *src.shape[:2])
 ctx = Context(0); ctx.set_profiling(True)
+d_en = ctx.to_device(tgt_en)
+for rep in range(a.reps):   # A11 on the device: the same unique set and inverse index as np.unique
+    t0 = time.perf_counter(); d_u, d_inv = ctx.unique_points(d_en); ctx.synchronize(); t_dev_unique = time.perf_counter() - t0
+assert np.array_equal(d_u.numpy(), tgt)
 d_src, d_tgt, d_f = ctx.to_device(src), ctx.to_device(tgt), ctx.to_device(fields)
 cen = ctx.to_device(src.mean(axis=1))
 res = {}
@@ -28,6 +32,6 @@ for rep in range(a.reps):
     t0 = time.perf_counter(); vals = ctx.gather_elem(d_f, elem, co); ctx.synchronize(); res["gather_ms"] = (time.perf_counter()-t0)*1e3
 v = vals.numpy()[:, 0]
 res.update(n_src_elem=int(src.shape[0]), P=int(src.shape[1]), n_targets=int(len(tgt)), missing=int(miss),
-           host_unique_s=round(t_unique, 2), max_err=float(np.abs(v - synth.field_smooth(tgt)).max()))
+           host_unique_s=round(t_unique, 2), device_unique_ms=round(t_dev_unique * 1e3, 2), element_nodal_points=int(len(tgt_en)), max_err=float(np.abs(v - synth.field_smooth(tgt)).max()))
 res["points_per_s"] = len(tgt) / ((res["knn_build_ms"] + res["knn_query_ms"] + res["locate_ms"] + res["gather_ms"]) * 1e-3)
 print(json.dumps(res))
