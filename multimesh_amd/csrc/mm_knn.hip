@@ -927,6 +927,12 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                                                              int dbg_stop)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
+#ifndef MM_STRIP_NB_SMALL   // tuning builds only
+#define MM_STRIP_NB_SMALL 32
+#endif
+    // histogram buckets: short lists need less resolution (the two buckets collected beyond the k-th
+    // distance hold ~1.5 k / buckets * 2.2 candidates each)
+    constexpr int kNB = K <= 8 ? MM_STRIP_NB_SMALL : kHistBuckets;
     // The tile holds the sources in PAIRS, {x0,x1,y0,y1}{z0,z1,w0,w1} (w = position in the sorted
     // array), so that P1 evaluates two candidates per packed-fp32 instruction.  Every layer starts
     // at an even entry (an odd layer is padded with one far-away sentinel).  Slots past the end of
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     // Each hand-over is separated by a wave_sync() from the last use of the other member.
     constexpr int kBdStride = CAP | 1;                 // doubles per group (odd)
     constexpr int kBxStride = (CAP + 7) / 4 * 4;       // ints per group (rows stay 16-byte aligned)
-    constexpr int kHistStride = kHistBuckets + 1;      // words per group (odd)
+    constexpr int kHistStride = kNB + 1;      // words per group (odd)
     constexpr int kPkBytes = (kStripSlots / 4) * kWave * 4, kBdBytes = kStripGroups * kBdStride * 8;
     constexpr int kHistBytes = kStripGroups * kHistStride * 4, kBxBytes = kStripGroups * kBxStride * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem0[kPkBytes > kBdBytes ? kPkBytes : kBdBytes];
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     // issued before the tile loads so that both are in flight together
     double npx, npy, npz, npw;
     {
-        int S1 = kWave;
+        int S1 = kWave < kNB ? kWave : kNB;
         while (S1 > kWave / kStripGroups && kWave / S1 < tn) S1 >>= 1;
         const int tg1 = lane / S1;
         const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (tg1 < tn ? tg1 : 0)) * kRec);
@@ -1099,13 +1105,13 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     for (int r0 = 0; r0 < tn; r0 += tpw) {
         // lanes per target: the widest split whose round still covers the remaining targets
         const int rem = tn - r0;
-        int S = kWave;
+        int S = kWave < kNB ? kWave : kNB;
         while (S > kWave / kStripGroups && kWave / S < rem) S >>= 1;
         tpw = kWave / S;
         const int tg = lane / S;         // this lane's target slot in the round
         const int sl = lane % S;         // this lane's slice of the window
         const int nbatch = (maxwin + U * S - 1) / (U * S);
-        const int bpl = kHistBuckets / S;  // histogram buckets per lane in the scan (S = 64 -> 1)
+        const int bpl = kNB / S;  // histogram buckets per lane in the scan (S = 64 -> 1)
         const bool valid = tg < rem;
         const double px = valid ? npx : ox;
         const double py = valid ? npy : oy;
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (rem > tpw) {
             // next round's targets (its split may be wider), in flight during this round
             const int rem2 = rem - tpw;
-            int S2 = kWave;
+            int S2 = kWave < kNB ? kWave : kNB;
             while (S2 > kWave / kStripGroups && kWave / S2 < rem2) S2 >>= 1;
             const int tg2 = lane / S2;
             const double2 *r2 =
@@ -1125,9 +1131,9 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             npz = zw.x;
             npw = zw.y;
         }
-        for (int q = lane; q < (kHistBuckets + 1) * kStripGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
+        for (int q = lane; q < (kNB + 1) * kStripGroups; q += kWave) (&s_hist[0][0])[q] = 0u;
         if (lane < kStripGroups) {
-            s_jb[lane] = kHistBuckets;
+            s_jb[lane] = kNB;
             s_seen[lane] = 0ull;
         }
         const int czl = min(max(cell_coord(pz, g.loz, g.ihz, g.nz), cz0), cz1 - 1);
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             else if (dims == 2) r2 = frac * vol * (1.f / 3.14159f);
             else if (dims == 1) { const float r = frac * vol * 0.5f; r2 = r * r; }
             else r2 = 1.f;
-            scale = (float)kHistBuckets / (2.2f * r2);
+            scale = (float)kNB / (2.2f * r2);
         }
         bool hand_over = !(scale > 0.f && scale < INFINITY) || we - ws < kout || we - ws > kTileCap;
         if (!(scale > 0.f && scale < INFINITY)) scale = 1.f;
@@ -1181,10 +1187,10 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                 // NaN -> last bucket (fminf returns the non-NaN operand).  The last bucket means
                 // "beyond the histogram range": most candidates land there, and counting them
                 // would serialise the LDS atomic on one address, so they are not counted.
-                const int b0 = (int)fminf(sc.x, (float)(kHistBuckets - 1));
-                const int b1 = (int)fminf(sc.y, (float)(kHistBuckets - 1));
-                if (b0 < kHistBuckets - 1) atomicAdd(&s_hist[tg][b0], 1u);
-                if (b1 < kHistBuckets - 1) atomicAdd(&s_hist[tg][b1], 1u);
+                const int b0 = (int)fminf(sc.x, (float)(kNB - 1));
+                const int b1 = (int)fminf(sc.y, (float)(kNB - 1));
+                if (b0 < kNB - 1) atomicAdd(&s_hist[tg][b0], 1u);
+                if (b1 < kNB - 1) atomicAdd(&s_hist[tg][b1], 1u);
                 packed |= ((unsigned)b0 | ((unsigned)b1 << 8)) << (16 * h);
             }
             s_pk[m][lane] = packed;
@@ -1210,7 +1216,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         }
         wave_sync();
         const int jb = s_jb[tg];
-        if (jb >= kHistBuckets - 2) hand_over = true;  // k-th distance beyond the histogram range
+        if (jb >= kNB - 2) hand_over = true;  // k-th distance beyond the histogram range
         {
             // every exact k-nearest candidate must land in a bucket <= jb+1 (cell kernel's header)
             const double e1 = (double)(jb + 1) / (double)scale;
@@ -1226,7 +1232,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         // its bucket is >= jb + 2, without carries; the multiply gathers the four flags)
         unsigned long long qmask = 0ull;
         {
-            const unsigned bias = (unsigned)(126 - min(jb, kHistBuckets)) * 0x01010101u;
+            const unsigned bias = (unsigned)(126 - min(jb, kNB)) * 0x01010101u;
             for (int m = 0; m < nbatch; ++m) {
                 const unsigned keep = (~(s_pk[m][lane] + bias) & 0x80808080u) >> 7;
                 qmask |= (unsigned long long)(((keep * 0x00204081u) >> 21) & 0xfu) << (m * U);
