@@ -933,6 +933,15 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     // histogram buckets: short lists need less resolution (the two buckets collected beyond the k-th
     // distance hold ~1.5 k / buckets * 2.2 candidates each)
     constexpr int kNB = K <= 8 ? MM_STRIP_NB_SMALL : kHistBuckets;
+    // log2 of the lanes per target: the widest split (at most one lane per histogram bucket) whose
+    // round still covers `left` targets, at least kWave / kStripGroups lanes
+    constexpr int kLgMax = kNB >= kWave ? 6 : (kNB >= 32 ? 5 : 4);
+    constexpr int kLgMin = kStripGroups == 8 ? 3 : (kStripGroups == 16 ? 2 : 4);
+    auto split_log2 = [](int left) {
+        int lg = kLgMax;
+        while (lg > kLgMin && (kWave >> lg) < left) --lg;
+        return lg;
+    };
     // The tile holds the sources in PAIRS, {x0,x1,y0,y1}{z0,z1,w0,w1} (w = position in the sorted
     // array), so that P1 evaluates two candidates per packed-fp32 instruction.  Every layer starts
     // at an even entry (an odd layer is padded with one far-away sentinel).  Slots past the end of
@@ -995,9 +1004,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     // issued before the tile loads so that both are in flight together
     double npx, npy, npz, npw;
     {
-        int S1 = kWave < kNB ? kWave : kNB;
-        while (S1 > kWave / kStripGroups && kWave / S1 < tn) S1 >>= 1;
-        const int tg1 = lane / S1;
+        const int tg1 = lane >> split_log2(tn);
         const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (tg1 < tn ? tg1 : 0)) * kRec);
         const double2 xy = r2[0], zw = r2[1];
         npx = xy.x;
@@ -1099,19 +1106,21 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (g.nz > 1) { ++dims; vol_layer *= (float)g.hz; }
     }
     constexpr int U = 4;
+    static_assert(U == 4, "nbatch uses a shift by log2(U)");
     constexpr double kU = 0x1p-24;
 
     int tpw = 0;
     for (int r0 = 0; r0 < tn; r0 += tpw) {
         // lanes per target: the widest split whose round still covers the remaining targets
         const int rem = tn - r0;
-        int S = kWave < kNB ? kWave : kNB;
-        while (S > kWave / kStripGroups && kWave / S < rem) S >>= 1;
-        tpw = kWave / S;
-        const int tg = lane / S;         // this lane's target slot in the round
-        const int sl = lane % S;         // this lane's slice of the window
-        const int nbatch = (maxwin + U * S - 1) / (U * S);
-        const int bpl = kNB / S;  // histogram buckets per lane in the scan (S = 64 -> 1)
+        // (S is a power of two: shifts, not the integer divisions a runtime S would cost)
+        const int lgS = split_log2(rem);
+        const int S = 1 << lgS;
+        tpw = kWave >> lgS;
+        const int tg = lane >> lgS;      // this lane's target slot in the round
+        const int sl = lane & (S - 1);   // this lane's slice of the window
+        const int nbatch = (maxwin + U * S - 1) >> (lgS + 2);   // U = 4
+        const int bpl = kNB >> lgS;      // histogram buckets per lane in the scan
         const bool valid = tg < rem;
         const double px = valid ? npx : ox;
         const double py = valid ? npy : oy;
@@ -1120,9 +1129,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (rem > tpw) {
             // next round's targets (its split may be wider), in flight during this round
             const int rem2 = rem - tpw;
-            int S2 = kWave < kNB ? kWave : kNB;
-            while (S2 > kWave / kStripGroups && kWave / S2 < rem2) S2 >>= 1;
-            const int tg2 = lane / S2;
+            const int tg2 = lane >> split_log2(rem2);
             const double2 *r2 =
                 reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + r0 + tpw + (tg2 < rem2 ? tg2 : 0)) * kRec);
             const double2 xy = r2[0], zw = r2[1];
@@ -1256,7 +1263,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         if (n > CAP) hand_over = true;
         int nmax = 0;
         for (int q = 0; q < tpw; ++q) nmax = max(nmax, min(s_cnt[q], CAP));
-        const int owned = (nmax + S - 1) / S;  // list entries per lane: sl, sl+S, ...
+        const int owned = (nmax + S - 1) >> lgS;  // list entries per lane: sl, sl+S, ...
 
         // ---- exact fp64 distance (reference arithmetic) and source id of the owned entries
         constexpr int MAXE = (CAP + kWave / kStripGroups - 1) / (kWave / kStripGroups);  // at the narrowest split
