@@ -1,6 +1,7 @@
 // The fused hot path on resident arrays (mm_interpolate_hex8) and the two LEGACY host-pointer
 // symbols that replace the reference's C library one for one (reference multi_mesh/helpers.py:43-81
 // binds them; reference scripts/cli.py:62-100 is the call sequence the fused entry reproduces).
+#include <cstdlib>
 #include <mutex>
 
 #include "mm_common.h"
@@ -14,6 +15,8 @@ void mm_clear_status(void);
 // candidates delivered up front when the lists are evaluated lazily (99.9 % of mesh-node targets are
 // resolved within them; see mm_set_lazy_lists)
 static const int64_t kLazyK = 8;
+// components up to which the gather is fused into the locate kernels (see mm_interpolate_hex8)
+static const int64_t kFuseGatherMaxComp = 3;   // measured at 10M targets: 1: -0.5 ms, 2: -0.3 ms, 3: even
 
 // -----------------------------------------------------------------------------------------
 // Fused pipeline: centroid -> grid build -> kNN -> locate -> gather.
@@ -64,11 +67,20 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)kq * sizeof(int), (void **)&nn);
     if (rc == MM_OK && kq < k)
         rc = mm_buffer_get(ctx, MM_BUF_NN_FULL, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn_full);
-    // The operator rows are only materialised when the caller asks for them (both pointers): the
-    // interpolated values are formed inside the locate stage, at the point of acceptance.
+    // Few components: the interpolated values are formed inside the locate stage, at the point of
+    // acceptance, and the operator rows are only materialised when the caller asks for them (both
+    // pointers).  Many components: 8 gathers per component inside the register-heavy locate kernel
+    // cost more than writing the rows and streaming them through the gather kernel.
+    const int64_t fuse_max = getenv("MM_FUSE_GATHER_MAXC") ? atoll(getenv("MM_FUSE_GATHER_MAXC")) : kFuseGatherMaxComp;
+    const bool want_values = out_d && ncomp > 0;
+    const bool fuse_gather = want_values && ncomp <= fuse_max;
     if (!(enc && w)) {
         enc = nullptr;
         w = nullptr;
+        if (want_values && !fuse_gather) {
+            if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * 8 * sizeof(i64), (void **)&enc);
+            if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * 8 * sizeof(double), (void **)&w);
+        }
     }
     if (rc != MM_OK) { result = rc; goto done; }
 
@@ -99,10 +111,16 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     lazy.nn_full = nn_full;
     rc = mm_launch_locate_hex8(ctx, kq, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
                                nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1,
-                               (out_d && ncomp > 0) ? fields_d : nullptr, nnodes, ncomp, out_d,
+                               fuse_gather ? fields_d : nullptr, nnodes, ncomp, out_d,
                                kq < k ? &lazy : nullptr);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) { result = rc; goto done; }
+    if (want_values && !fuse_gather) {
+        mm_stage_begin(ctx, MM_STAGE_GATHER);
+        rc = mm_launch_gather(ctx, fields_d, nnodes, ncomp, enc, w, npoints, 8, out_d, 1);
+        mm_stage_end(ctx, MM_STAGE_GATHER);
+        if (rc != MM_OK) { result = rc; goto done; }
+    }
 
     e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

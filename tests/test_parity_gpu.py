@@ -255,6 +255,22 @@ def test_fused_pipeline_lazy_equals_eager_when_lists_run_out(ctx):
     assert np.array_equal(out[True][1][ok], enc_o[ok]) and np.array_equal(out[True][2][ok], w_o[ok])
 
 
+def test_fused_pipeline_many_components_uses_the_gather_kernel(ctx):
+    # more than 3 components: the values-only call writes the operator internally and streams it
+    # through the gather kernel instead of gathering inside the locate; same bits either way
+    pa, ca = synth.hex_mesh(30, seed=1)
+    pb, _ = synth.hex_mesh(33, seed=7)
+    base = synth.vector_field(pa)
+    fields = np.ascontiguousarray(np.concatenate([base, base[::-1] * 0.5]))      # C = 6
+    vals, nf = ctx.interpolate_hex8(pa, ca, pb, fields)
+    assert nf == 0 and vals.shape == (len(pb), 6)
+    vals3, _ = ctx.interpolate_hex8(pa, ca, pb, fields[:3])                      # fused path
+    assert np.array_equal(vals.numpy()[:, :3], vals3.numpy())
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+    assert np.array_equal(vals.numpy(), O.gather(fields, enc_o, w_o))
+
+
 def test_fused_pipeline_structured_ties(ctx, golden):
     # exact kNN ties: candidate order (hence the chosen element on shared faces) is unspecified in
     # the reference; the interpolated values still agree to rounding.  Tolerance: 1e-13 absolute.
