@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         // histogram range from the density of the target's own window: the ball holding k of the
         // window's sources has r^d = (k/count) * V_block / c_d; buckets are uniform in r^2 over
         // [0, 2.2 r^2).  Only a heuristic range, so fast exp2/log2 are fine.
-        float scale;
+        float scale, width;
         {
             const float vol = g.nz > 1 ? vol_layer * (float)(l1 - l0) : vol_layer;
             const float frac = (float)kout / (float)max(we - ws, 1);
@@ -1163,10 +1163,13 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             else if (dims == 2) r2 = frac * vol * (1.f / 3.14159f);
             else if (dims == 1) { const float r = frac * vol * 0.5f; r2 = r * r; }
             else r2 = 1.f;
-            scale = (float)kNB / (2.2f * r2);
+            // bucket width first (the division by the power-of-two bucket count is exact), the binning
+            // factor is its correctly rounded reciprocal: 1/scale = width (1 +- 2u)
+            width = 2.2f * r2 * (1.f / (float)kNB);
+            scale = 1.f / width;
         }
         bool hand_over = !(scale > 0.f && scale < INFINITY) || we - ws < kout || we - ws > kTileCap;
-        if (!(scale > 0.f && scale < INFINITY)) scale = 1.f;
+        if (!(scale > 0.f && scale < INFINITY)) scale = width = 1.f;
         wave_sync();  // counters cleared
 
         // ---- P1: histogram of fp32 squared distances (two candidates per packed instruction); the
@@ -1225,10 +1228,14 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         const int jb = s_jb[tg];
         if (jb >= kNB - 2) hand_over = true;  // k-th distance beyond the histogram range
         {
-            // every exact k-nearest candidate must land in a bucket <= jb+1 (cell kernel's header)
-            const double e1 = (double)(jb + 1) / (double)scale;
-            const double e2 = (double)(jb + 2) / (double)scale;
-            const double D = sqrt(e1) * (1.0 + 4.0 * kU) + E;
+            // every exact k-nearest candidate must land in a bucket <= jb+1 (cell kernel's header).  No
+            // fp64 division or square root here (once per target and round, they were a tenth of the
+            // round's instructions): e1 >= (jb+1)/scale and e2 <= (jb+2)/scale from the bucket width,
+            // and an fp32 square root rounded up bounds sqrt(e1) from above.
+            const double e1 = (double)(jb + 1) * (double)width * (1.0 + 4.0 * kU);
+            const double e2 = (double)(jb + 2) * (double)width * (1.0 - 4.0 * kU);
+            const double root = (double)__builtin_sqrtf((float)(e1 * (1.0 + 2.0 * kU))) * (1.0 + 4.0 * kU);
+            const double D = root * (1.0 + 4.0 * kU) + E;
             const double D2 = D * (1.0 + 4.0 * kU) + E;
             if (!(D2 * D2 * (1.0 + 8.0 * kU) < e2)) hand_over = true;
         }
