@@ -110,48 +110,66 @@ struct Gll {
 #pragma unroll
                 for (int b = 0; b < DIM; ++b) J[a][b] = 0.0;
             }
+            // Tensor-product (sum-factorised) evaluation of the map and its Jacobian, in exactly the
+            // oracle's order of partial sums (mmo_gll_inverse_transform): innermost over i with l0 /
+            // dl0, then over j, then over k -- 2.1 k instead of 4 k fp64 operations per step at order 4
+            // and a third of the live registers.
             if (DIM == 3) {
 #pragma unroll
-                for (int k = 0; k < n; ++k)
+                for (int k = 0; k < n; ++k) {
+                    double b00[3] = {0.0, 0.0, 0.0}, b01[3] = {0.0, 0.0, 0.0}, b10[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                     for (int j = 0; j < n; ++j) {
                         // keep the scheduler from hoisting all (order+1)^3 node loads to the top of
-                        // the unrolled loop (256 VGPRs, one wave per SIMD): one row of nodes at a time
+                        // the unrolled loop: one row of nodes at a time
                         asm volatile("" ::: "memory");
+                        double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                         for (int i = 0; i < n; ++i) {
                             const double *X = ctrl + 3 * (i + n * (j + n * k));
-                            const double w = (l[0][i] * l[1][j]) * l[DIM - 1][k];
-                            const double g0 = (dl[0][i] * l[1][j]) * l[DIM - 1][k];
-                            const double g1 = (l[0][i] * dl[1][j]) * l[DIM - 1][k];
-                            const double g2 = (l[0][i] * l[1][j]) * dl[DIM - 1][k];
 #pragma unroll
-                            for (int a = 0; a < DIM; ++a) {
+                            for (int a = 0; a < 3; ++a) {
                                 const double Xa = X[a];
-                                x[a] = x[a] + w * Xa;
-                                J[a][0] = J[a][0] + g0 * Xa;
-                                J[a][1] = J[a][1] + g1 * Xa;
-                                J[a][DIM - 1] = J[a][DIM - 1] + g2 * Xa;
+                                a0[a] = a0[a] + l[0][i] * Xa;
+                                a1[a] = a1[a] + dl[0][i] * Xa;
                             }
                         }
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            b00[a] = b00[a] + l[1][j] * a0[a];
+                            b01[a] = b01[a] + dl[1][j] * a0[a];
+                            b10[a] = b10[a] + l[1][j] * a1[a];
+                        }
                     }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        x[a] = x[a] + l[DIM - 1][k] * b00[a];
+                        J[a][0] = J[a][0] + l[DIM - 1][k] * b10[a];
+                        J[a][1] = J[a][1] + l[DIM - 1][k] * b01[a];
+                        J[a][DIM - 1] = J[a][DIM - 1] + dl[DIM - 1][k] * b00[a];
+                    }
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < n; ++j)
+                for (int j = 0; j < n; ++j) {
+                    double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
 #pragma unroll
                     for (int i = 0; i < n; ++i) {
                         const double *X = ctrl + 2 * (i + n * j);
-                        const double w = l[0][i] * l[1][j];
-                        const double g0 = dl[0][i] * l[1][j];
-                        const double g1 = l[0][i] * dl[1][j];
 #pragma unroll
-                        for (int a = 0; a < DIM; ++a) {
+                        for (int a = 0; a < 2; ++a) {
                             const double Xa = X[a];
-                            x[a] = x[a] + w * Xa;
-                            J[a][0] = J[a][0] + g0 * Xa;
-                            J[a][1] = J[a][1] + g1 * Xa;
+                            a0[a] = a0[a] + l[0][i] * Xa;
+                            a1[a] = a1[a] + dl[0][i] * Xa;
                         }
                     }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        x[a] = x[a] + l[1][j] * a0[a];
+                        J[a][0] = J[a][0] + l[1][j] * a1[a];
+                        J[a][1] = J[a][1] + dl[1][j] * a0[a];
+                    }
+                }
             }
             double r[DIM], dxi[DIM];
 #pragma unroll
@@ -228,7 +246,7 @@ struct Gll {
 constexpr int kGllWaveQueue = 256;
 
 template <int ORDER, int DIM>
-__global__ __launch_bounds__(64) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+__global__ __launch_bounds__(64, 2) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
                                                              const double *__restrict__ gll_points, i64 nelem,
                                                              const double *__restrict__ points, double tolerance,
                                                              int snap_to_nearest, i64 *__restrict__ elem,

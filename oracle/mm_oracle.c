@@ -451,35 +451,50 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
     for (int it = 0; it < 25; ++it) {
         for (int d = 0; d < dim; ++d) lagrange_1d(order, g, xi[d], l[d], dl[d]);
         double x[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        /* Tensor-product (sum-factorised) evaluation of the map and its Jacobian; the order of the
+         * partial sums below IS the definition of this path's arithmetic (the HIP kernel follows it
+         * operation for operation): innermost over i with l0 / dl0, then over j, then over k. */
         if (dim == 3) {
-            for (int k = 0; k < n; ++k)
-                for (int j = 0; j < n; ++j)
+            for (int k = 0; k < n; ++k) {
+                double b00[3] = {0, 0, 0}, b01[3] = {0, 0, 0}, b10[3] = {0, 0, 0};
+                for (int j = 0; j < n; ++j) {
+                    double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
                     for (int i = 0; i < n; ++i) {
                         const double *X = ctrl + 3 * (i + n * (j + n * k));
-                        const double w = (l[0][i] * l[1][j]) * l[2][k];
-                        const double g0 = (dl[0][i] * l[1][j]) * l[2][k];
-                        const double g1 = (l[0][i] * dl[1][j]) * l[2][k];
-                        const double g2 = (l[0][i] * l[1][j]) * dl[2][k];
                         for (int a = 0; a < 3; ++a) {
-                            x[a] = x[a] + w * X[a];
-                            J[a][0] = J[a][0] + g0 * X[a];
-                            J[a][1] = J[a][1] + g1 * X[a];
-                            J[a][2] = J[a][2] + g2 * X[a];
+                            a0[a] = a0[a] + l[0][i] * X[a];
+                            a1[a] = a1[a] + dl[0][i] * X[a];
                         }
                     }
-        } else {
-            for (int j = 0; j < n; ++j)
-                for (int i = 0; i < n; ++i) {
-                    const double *X = ctrl + 2 * (i + n * j);
-                    const double w = l[0][i] * l[1][j];
-                    const double g0 = dl[0][i] * l[1][j];
-                    const double g1 = l[0][i] * dl[1][j];
-                    for (int a = 0; a < 2; ++a) {
-                        x[a] = x[a] + w * X[a];
-                        J[a][0] = J[a][0] + g0 * X[a];
-                        J[a][1] = J[a][1] + g1 * X[a];
+                    for (int a = 0; a < 3; ++a) {
+                        b00[a] = b00[a] + l[1][j] * a0[a];
+                        b01[a] = b01[a] + dl[1][j] * a0[a];
+                        b10[a] = b10[a] + l[1][j] * a1[a];
                     }
                 }
+                for (int a = 0; a < 3; ++a) {
+                    x[a] = x[a] + l[2][k] * b00[a];
+                    J[a][0] = J[a][0] + l[2][k] * b10[a];
+                    J[a][1] = J[a][1] + l[2][k] * b01[a];
+                    J[a][2] = J[a][2] + dl[2][k] * b00[a];
+                }
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                double a0[2] = {0, 0}, a1[2] = {0, 0};
+                for (int i = 0; i < n; ++i) {
+                    const double *X = ctrl + 2 * (i + n * j);
+                    for (int a = 0; a < 2; ++a) {
+                        a0[a] = a0[a] + l[0][i] * X[a];
+                        a1[a] = a1[a] + dl[0][i] * X[a];
+                    }
+                }
+                for (int a = 0; a < 2; ++a) {
+                    x[a] = x[a] + l[1][j] * a0[a];
+                    J[a][0] = J[a][0] + l[1][j] * a1[a];
+                    J[a][1] = J[a][1] + dl[1][j] * a0[a];
+                }
+            }
         }
         double r[3] = {0, 0, 0}, dxi[3] = {0, 0, 0};
         for (int a = 0; a < dim; ++a) r[a] = x[a] - pnt[a];
