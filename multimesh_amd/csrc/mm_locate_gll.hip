@@ -246,7 +246,7 @@ struct Gll {
 constexpr int kGllWaveQueue = 256;
 
 template <int ORDER, int DIM>
-__global__ __launch_bounds__(64, 2) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+__global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
                                                              const double *__restrict__ gll_points, i64 nelem,
                                                              const double *__restrict__ points, double tolerance,
                                                              int snap_to_nearest, i64 *__restrict__ elem,
