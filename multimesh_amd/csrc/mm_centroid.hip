@@ -41,6 +41,66 @@ __global__ __launch_bounds__(256) void centroid_kernel(i64 nelem, i64 nper_rt,
     for (int a = 0; a < NDIM; ++a) out[e * NDIM + a] = acc[a] / denom;
 }
 
+// Fused-pipeline variant (hex8, 3-D): the same centroids, and each workgroup also leaves the bounding
+// box of the centroids it produced in partial[block][6] (min x,y,z, max x,y,z) -- the search grid of
+// the next stage is sized from that box, and taking it here saves a pass over the centroid array.
+// Grid-stride over the elements so that the number of partials stays small.
+__global__ __launch_bounds__(256) void centroid_bbox_kernel(i64 nelem, const i64 *__restrict__ conn,
+                                                            const double *__restrict__ points,
+                                                            double *__restrict__ out, double *__restrict__ partial)
+{
+    __shared__ double s_box[6][256 / 64];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (i64)gridDim.x * blockDim.x) {
+        const i64 *row = conn + e * 8;
+        i64 id[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) id[p] = row[p];
+        double acc[3] = {0., 0., 0.};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = acc[a] + points[id[p] * 3 + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double c = acc[a] / 8.0;   // summed in connectivity order from 0.0, divided (centroid.c:17-22)
+            out[e * 3 + a] = c;
+            mn[a] = fmin(mn[a], c);
+            mx[a] = fmax(mx[a], c);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fmin(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmax(mx[a], __shfl_xor(mx[a], off));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_box[a][wave] = mn[a];
+            s_box[3 + a][wave] = mx[a];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = s_box[threadIdx.x][0];
+        for (int w = 1; w < 256 / 64; ++w) v = threadIdx.x < 3 ? fmin(v, s_box[threadIdx.x][w]) : fmax(v, s_box[threadIdx.x][w]);
+        partial[(i64)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+int mm_launch_centroid_bbox(mm_context *ctx, i64 nelem, const i64 *conn, const double *points, double *out,
+                            double *partial, int nblocks)
+{
+    if (nelem == 0) return MM_OK;
+    hipLaunchKernelGGL(centroid_bbox_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, nelem, conn, points,
+                       out, partial);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
 int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,
                        const double *points, double *out)
 {

@@ -47,6 +47,7 @@ enum mm_buffer_slot {
     MM_BUF_CELL_START,
     MM_BUF_SORTED_XYZ,
     MM_BUF_NN_FULL,
+    MM_BUF_BOX_PARTIAL,
     MM_BUF_COUNT
 };
 
@@ -85,6 +86,9 @@ void mm_stage_end(mm_context *ctx, int stage);
 // ---- internal launchers (device pointers, no synchronisation) -------------------------
 int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,
                        const double *points, double *out);
+// hex8 centroids + per-workgroup bounding boxes partial[nblocks][6] of them (fused pipeline)
+int mm_launch_centroid_bbox(mm_context *ctx, i64 nelem, const i64 *conn, const double *points, double *out,
+                            double *partial, int nblocks);
 // enc/w: operator rows (may be null when out is given); fields [ncomp][nnodes] + out [npoints][ncomp]:
 // interpolated values formed at the acceptance point (the gather fused into the locate), or null
 // lazy (nullable): nn holds only the k nearest of k_full; targets that exhaust them get their full

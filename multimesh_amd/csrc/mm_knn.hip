@@ -1492,7 +1492,7 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
 
 // Build without touching the stage timers (used by the fused pipeline too).
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers)
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks)
 {
     *out = nullptr;
     mm_knn_index *ix = new (std::nothrow) mm_knn_index();
@@ -1511,9 +1511,14 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         if (rc != MM_OK) { delete ix; return rc; }
         double *partial = (double *)mm_scratch_take(ctx, (size_t)nblocks * 6 * sizeof(double));
         double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
-        hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim,
-                           partial);
-        hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
+        if (box_partial_d) {
+            // the producer of the sources (the fused pipeline's centroid kernel) already left partials
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
+        } else {
+            hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
+                               (int)ndim, partial);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
+        }
         hipError_t e = hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -1716,7 +1721,7 @@ extern "C" int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, 
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out, false);
+    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out, false, nullptr, 0);
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     return rc;
 }

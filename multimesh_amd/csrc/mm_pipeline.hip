@@ -7,7 +7,7 @@
 #include "mm_common.h"
 
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers);
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks);
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
                       double *dist_d, bool idx_is_int32);
 void mm_clear_status(void);
@@ -15,6 +15,8 @@ void mm_clear_status(void);
 // candidates delivered up front when the lists are evaluated lazily (99.9 % of mesh-node targets are
 // resolved within them; see mm_set_lazy_lists)
 static const int64_t kLazyK = 8;
+// workgroups of the fused centroid + bounding-box kernel (grid-stride; one partial box each)
+static const int kBoxBlocks = 2048;
 // components up to which the gather is fused into the locate kernels (see mm_interpolate_hex8)
 static const int64_t kFuseGatherMaxComp = 3;   // measured at 10M targets: 1: -0.5 ms, 2: -0.3 ms, 3: even
 
@@ -42,7 +44,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
 
     // Intermediates come from the context's grow-only buffer cache: after the first call with a
     // given problem size there is no allocation, free or extra synchronisation in here.
-    double *cen = nullptr;
+    double *cen = nullptr, *box_partial = nullptr;
     int *nn = nullptr;  // candidate lists stay int32 inside the pipeline (half the bytes of the public int64)
     i64 *enc = (i64 *)enc_d;
     double *w = w_d;
@@ -64,6 +66,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     int *nn_full = nullptr;
     mm_lazy_lists lazy;
     rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
+    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_BOX_PARTIAL, (size_t)kBoxBlocks * 6 * sizeof(double), (void **)&box_partial);
     if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)kq * sizeof(int), (void **)&nn);
     if (rc == MM_OK && kq < k)
         rc = mm_buffer_get(ctx, MM_BUF_NN_FULL, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn_full);
@@ -89,12 +92,12 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     // writes them (no 1.3 GB memset up front)
 
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
-    rc = mm_launch_centroid(ctx, 3, nelem, 8, (const i64 *)conn_d, nodes_d, cen);
+    rc = mm_launch_centroid_bbox(ctx, nelem, (const i64 *)conn_d, nodes_d, cen, box_partial, kBoxBlocks);
     mm_stage_end(ctx, MM_STAGE_CENTROID);
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true);
+    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true, box_partial, kBoxBlocks);
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     if (rc != MM_OK) { result = rc; goto done; }
 
