@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, 
         i64 i = 0;
         int j = 0;
         int cap = kPassIters;  // retries from the wave's queue are ordinary solves
+        int lgG = 0;           // log2 of the lanes per target (only the drain rounds work ahead)
         if (held >= 64) {
             held -= 64;
             const int2 e = my_queue[held + lane];
@@ -396,75 +397,105 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, 
             next += nwaves * 64;
             cap = fresh_cap;  // a long launch resumes parked solves with the reference's cap
         } else if (held > 0) {
-            // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...:
-            // a handful of short rounds at the very end of the pass instead of another pass)
-            active = lane < held;
+            // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
+            // handful of short rounds at the very end of the pass instead of another pass).  The idle
+            // lanes work ahead: with at most 32 (16) targets left, 2 (4) lanes per target try its
+            // next 2 (4) candidates at once, which shortens the chain of rounds a hard target needs;
+            // the group then acts on the first candidate, in order, that is not a plain rejection.
+            lgG = held <= 16 ? 2 : (held <= 32 ? 1 : 0);
+            const int entry = lane >> lgG;
+            active = entry < held;
             if (active) {
-                const int2 e = my_queue[lane];
+                const int2 e = my_queue[entry];
                 i = e.x;
-                j = e.y;
+                j = e.y + (lane & ((1 << lgG) - 1));
             }
             held = 0;
         } else {
             break;
         }
         wave_fence();  // the queue reads above happen before this round's appends
-        bool requeue = false, go_long = false;
+        // outcome of this lane's candidate: 0 rejected, 1 accepted, 2 too slow for this cap (park),
+        // 3 no candidate left
+        int outcome = 0;
+        Corners c;
+        double wt[8];
         if (active) {
             const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
-            Corners c;
-            // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point
+            // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point (a lane
+            // that works ahead looks at its one candidate only: outside the box = rejected)
             bool have = false;
             for (; j < k; ++j) {
                 const i64 elem = (i64)nn[i * k + j];
-                if (nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem) continue;
-                load_corners<EXODUS>(conn, nodes, elem, c);
-                double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
+                const bool valid_elem = !(nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem);
+                bool outside = true;
+                if (valid_elem) {
+                    load_corners<EXODUS>(conn, nodes, elem, c);
+                    double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
 #pragma unroll
-                for (int n = 1; n < 8; ++n) {
-                    xlo = fmin(xlo, c.x[n]);
-                    xhi = fmax(xhi, c.x[n]);
-                    ylo = fmin(ylo, c.y[n]);
-                    yhi = fmax(yhi, c.y[n]);
+                    for (int n = 1; n < 8; ++n) {
+                        xlo = fmin(xlo, c.x[n]);
+                        xhi = fmax(xhi, c.x[n]);
+                        ylo = fmin(ylo, c.y[n]);
+                        yhi = fmax(yhi, c.y[n]);
+                    }
+                    const double mx = 0.05 * (xhi - xlo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+                    const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
+                    // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
+                    outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
                 }
-                const double mx = 0.05 * (xhi - xlo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
-                const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
-                // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
-                const bool outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
                 if (!outside) {
                     have = true;
                     break;
                 }
+                if (lgG > 0) break;  // working ahead: this one candidate only
             }
-            if (!have) {
-                // no candidate left that could be accepted: fallback / failure is the reference's call
-                slow_list[atomicAdd(slow_count, 1)] = (int)i;
-            } else {
-                double xi[3], wt[8];
-                bool accepted = false;
+            if (j >= k) {
+                outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
+            } else if (have) {
+                double xi[3];
                 // A solve that has not converged within kPassIters iterations (p99 is 6) would hold the
                 // whole wave for up to 50; the target is parked, SAME candidate, for the next (long)
                 // launch, whose fresh entries run with the reference's own cap of 50 -- there slow solves
                 // only keep each other company, and "not converged" means the candidate is rejected.
                 const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap);
-                if (converged && in_hull(xi)) {
-                    if (max_abs3(xi) < (1 + 0.025)) {
-                        weights_hex8(xi, wt);
-                        emit_row(em, i, c.id, wt);
-                        accepted = true;
-                    }
+                if (converged && in_hull(xi) && max_abs3(xi) < (1 + 0.025)) {
+                    weights_hex8(xi, wt);
+                    outcome = 1;
+                } else if (!converged && cap < 50) {
+                    outcome = 2;
                 }
-                if (!accepted) {
-                    if (!converged && cap < 50) go_long = true;
-                    else if (j + 1 < k) requeue = true;
-                    else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+            }
+        }
+        // the first lane of a target's group (the whole group when nobody works ahead) whose outcome is
+        // not a rejection decides; if all rejected, the group's first lane moves on behind the group
+        bool requeue = false, go_long = false;
+        int requeue_j = 0;
+        {
+            const int G = 1 << lgG;
+            const unsigned long long decisive = __ballot(active && outcome != 0);
+            const int group_base = lane & ~(G - 1);
+            const unsigned long long mine = (decisive >> group_base) & ((1ull << G) - 1ull);
+            const int first = mine ? __ffsll((long long)mine) - 1 : G;
+            const int g = lane - group_base;
+            if (active && g == first) {
+                if (outcome == 1) emit_row(em, i, c.id, wt);
+                else if (outcome == 2) go_long = true;
+                else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+            } else if (active && first == G && g == 0) {
+                // every candidate of the group rejected (j is this lane's, the group's first)
+                if (j + G < k) {
+                    requeue = true;
+                    requeue_j = j + G;
+                } else {
+                    slow_list[atomicAdd(slow_count, 1)] = (int)i;
                 }
             }
         }
         // unresolved targets go to the wave's own queue (slot = ballot prefix, no atomics); fewer than
         // 64 were waiting and at most 64 are added, so kWaveQueue = 128 entries suffice
         const unsigned long long vote = __ballot(requeue);
-        if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j + 1);
+        if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, requeue_j);
         held += __popcll(vote);
         {
             const unsigned long long lvote = __ballot(go_long);
