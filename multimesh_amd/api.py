@@ -233,6 +233,25 @@ def interpolate_gll_to_gll(mesh_a: GllMesh, target_gll_points, params_to_interp,
     return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(params_to_interp), tgt.shape[0], tgt.shape[1])
 
 
+def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to_search=20, context=None):
+    """The array core of ``exodus_2_gll`` (reference cli.py:128-257, interpolator.py:60-150): the
+    reference runs its hex8 path once per GLL slot (125 times at order 4) over points that repeat on
+    shared faces, edges and corners; here the target mesh's element-nodal points are reduced to
+    their unique set on the device, interpolated once each through the hex8 pipeline, and scattered
+    back with the inverse index.  ``target_gll_points`` f64[E_t, P_t, 3] -> f64[C, E_t, P_t]; points
+    that are not found get zero."""
+    ctx = context or default_context()
+    tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
+    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]))
+    vals, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, uniq, mesh_a.fields_matrix(list(params)),
+                                         nelem_to_search=nelem_to_search)
+    if nfailed > 0:
+        print(nfailed, "points could not find an enclosing element. These points will be set to zero. "
+                       "Please check your domain or the interpolation tuning parameters")
+    vals = vals.numpy()                                              # [U, C]
+    return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(list(params)), tgt.shape[0], tgt.shape[1])
+
+
 def _gll(name, row):
     def f(*args, **kwargs):
         raise NotImplementedError(f"{name}: the GLL (salvus.fem backed) path is SURVEY.md §8 row {row}; "
@@ -241,10 +260,10 @@ def _gll(name, row):
     return f
 
 
-exodus_2_gll = _gll("exodus_2_gll", "A10 / §8f-2")
+exodus_2_gll = _gll("exodus_2_gll", "§8f-2 (file I/O) -- array core: interpolate_hex8_to_gll")
 gll_2_gll = _gll("gll_2_gll", "A10 -- array core: interpolate_gll_to_gll; file I/O is §8f-2")
 gll_2_gll_layered = _gll("gll_2_gll_layered", "A10 / §8f-4")
 gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "A10 / §8f-4")
 gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "A10 / §8f-4")
-gll_2_exodus = _gll("gll_2_exodus", "A10 / §8f-2")
+gll_2_exodus = _gll("gll_2_exodus", "§8f-2 (file I/O) -- array core: interpolate_gll_to_points")
 query_model = _gll("query_model", "A10")

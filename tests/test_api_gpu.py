@@ -167,3 +167,18 @@ def test_gll_to_gll_on_arrays_reproduces_a_polynomial():
     out = api.interpolate_gll_to_gll(mesh, tgt, ["f"])
     assert out.shape == (1,) + tgt.shape[:2]
     assert np.abs(out[0] - poly(tgt)).max() < 1e-9          # inside the order-4 space: exact to rounding
+
+
+@pytest.mark.gpu
+def test_hex8_to_gll_on_arrays_equals_the_pointwise_path():
+    # exodus_2_gll's array core: unique GLL targets through the hex8 pipeline, scattered back
+    from multimesh_amd import api, synth
+    from multimesh_amd.mesh import HexMesh
+    pa, ca = synth.hex_mesh(20, seed=1)
+    mesh = HexMesh(pa, ca, {"f1": synth.field_linear(pa), "f2": synth.field_smooth(pa)})
+    tgt = synth.gll_mesh(7, 4, seed=7, dim=3)
+    out = api.interpolate_hex8_to_gll(mesh, tgt, ["f1", "f2"])
+    assert out.shape == (2,) + tgt.shape[:2]
+    flat = api.interpolate_to_points(mesh, tgt.reshape(-1, 3), ["f1", "f2"], nelem_to_search=20)
+    assert np.array_equal(out.reshape(2, -1).T, flat)               # same bits as one call per point
+    assert np.abs(out[0] - synth.field_linear(tgt)).max() < 1e-7    # trilinear field reproduced
