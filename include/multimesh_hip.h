@@ -138,6 +138,18 @@ int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t nelem_to_sear
                       const double *points_d, double tolerance, int snap_to_nearest, int64_t *elem_d,
                       double *coeffs_d);
 
+/* The other GLL acceptance loop of the reference: _check_if_inside_element + boundary_box_check
+ * (components/interpolator.py:1350-1367, :1409-1473; used by gll_2_exodus :274, the layered drivers
+ * :543 and the helpers :1523, :1572).  Candidates in order: bounding box of the control nodes first,
+ * inside -> inverse transform, accept when every |xi| <= 1.04.  Otherwise the first candidate whose
+ * box holds the point, else the one with the nearest control-node mean, is transformed again; NaN
+ * or any |xi| >= 1.04 gives the reference's constant xi = (0.645, -0.5, 0.22) (:1468-1471).
+ * Arrays as mm_locate_gll; PARITY UNPINNED like it.  Returns the number of points whose final
+ * transform was NaN (where the reference raises unless ignore_hard_elements), or a negative MM_ERR_*. */
+int64_t mm_locate_gll_bbox(mm_context *ctx, int order, int dim, int64_t nelem_to_search, int64_t npoints,
+                           const int64_t *nearest_element_indices_d, const double *gll_points_d,
+                           int64_t nelem, const double *points_d, int64_t *elem_d, double *coeffs_d);
+
 /* Element-nodal gather np.sum(coeffs * field[elem_indices], axis=1) (reference interpolator.py:976):
  * fields_d f64[ncomp][nelem][P]; points with elem -1 give 0.  NumPy's summation order. */
 int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64_t ncomp,

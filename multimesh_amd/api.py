@@ -187,6 +187,16 @@ def get_element_weights(gll_points, shape_order, centroid_tree, points, nelem_to
     return elem.numpy(), coeffs.numpy()
 
 
+def check_if_inside_element(gll_model, nearest_elements, points, shape_order, context=None):
+    """Array form of the reference's ``_check_if_inside_element`` (interpolator.py:1409-1473, called
+    per point by gll_2_exodus and the layered drivers): bounding-box pre-test, acceptance at
+    |xi| <= 1.04, best-candidate fallback.  ``gll_model`` f64[E, P, dim], ``nearest_elements``
+    int64[N, k], ``points`` f64[N, dim] -> (element int64[N], coefficients f64[N, P])."""
+    ctx = context or default_context()
+    elem, coeffs, _ = ctx.locate_gll_bbox(shape_order, nearest_elements, gll_model, points)
+    return elem.numpy(), coeffs.numpy()
+
+
 def interpolate_gll_to_points(mesh: GllMesh, points, params_to_interp, nelem_to_search=25, tolerance=1.05,
                               context=None):
     """The GLL form of ``interpolate_to_points`` (reference interpolator.py:931-977): centroid tree,

@@ -450,6 +450,121 @@ void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const dou
     }
 }
 
+// ---- variant 1 (reference interpolator.py:1350-1367, :1409-1473; oracle mmo_locate_gll_v1) ----------
+// Per element: axis-aligned bounding box of the control nodes and their mean (sequential sum from 0.0
+// in node order, divided by P) -- boxes[e] = {min[dim], max[dim], centre[dim]}.  The reference
+// recomputes them per candidate and point; they only depend on the element.
+template <int ORDER, int DIM>
+__global__ __launch_bounds__(256) void gll_box_kernel(i64 nelem, const double *__restrict__ gll_points,
+                                                      double *__restrict__ boxes)
+{
+    constexpr int P = Gll<ORDER, DIM>::P;
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nelem) return;
+    const double *X = gll_points + e * (i64)(P * DIM);
+    double *b = boxes + e * (i64)(3 * DIM);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        double mn = X[d], mx = X[d], sum = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const double v = X[p * DIM + d];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+            sum = sum + v;
+        }
+        b[d] = mn;
+        b[DIM + d] = mx;
+        b[2 * DIM + d] = sum / (double)P;
+    }
+}
+
+// One lane per target, candidates in order (lock-step: this variant is the completeness path, the
+// tolerance/snap variant above is the tuned one).
+template <int ORDER, int DIM>
+__global__ __launch_bounds__(64, 3) void locate_gll_v1_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+                                                              const double *__restrict__ gll_points, i64 nelem,
+                                                              const double *__restrict__ boxes,
+                                                              const double *__restrict__ points,
+                                                              i64 *__restrict__ elem, double *__restrict__ coeffs,
+                                                              unsigned long long *__restrict__ nhard,
+                                                              const int *__restrict__ order)
+{
+    using G = Gll<ORDER, DIM>;
+    constexpr int P = G::P;
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hard = false;
+    if (q < npoints) {
+        const i64 i = order ? (i64)order[q] : q;
+        double pnt[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
+        i64 first_inside = -1, nearest = -1;
+        double nearest_d2 = INFINITY;
+        bool found = false;
+        double xi[DIM];
+        for (i64 j = 0; j < k && !found; ++j) {
+            const i64 e = nn[i * k + j];
+            if (e < 0 || e >= nelem) continue;
+            const double *b = boxes + e * (i64)(3 * DIM);
+            bool inside = true;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d)
+                if (!(pnt[d] >= b[d] && pnt[d] <= b[DIM + d])) inside = false;
+            if (inside) {
+                if (first_inside < 0) first_inside = j;
+                G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d)
+                    if (!(fabs(xi[d]) <= 1.04)) ok = false;   // NaN fails the comparison too
+                if (ok) {
+                    elem[i] = e;
+                    G::coefficients(xi, coeffs + i * P);
+                    found = true;
+                }
+            } else {
+                double d2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    const double t = pnt[d] - b[2 * DIM + d];
+                    d2 = d2 + t * t;
+                }
+                if (d2 < nearest_d2) {
+                    nearest_d2 = d2;
+                    nearest = j;
+                }
+            }
+        }
+        if (!found) {
+            const i64 ind = first_inside >= 0 ? first_inside : nearest;
+            if (ind < 0) {
+                elem[i] = -1;
+                for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                hard = true;
+            } else {
+                const i64 e = nn[i * k + ind];
+                G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
+                bool isnan_any = false, far = false;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    if (xi[d] != xi[d]) isnan_any = true;
+                    if (fabs(xi[d]) >= 1.04) far = true;
+                }
+                hard = isnan_any;
+                if (isnan_any || far) {
+                    const double hard_xi[3] = {0.645, -0.5, 0.22};   // reference :1468-1471
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) xi[d] = hard_xi[d];
+                }
+                elem[i] = e;
+                G::coefficients(xi, coeffs + i * P);
+            }
+        }
+    }
+    const unsigned long long mask = __ballot(hard);
+    if (threadIdx.x == 0 && mask) atomicAdd(nhard, (unsigned long long)__popcll(mask));
+}
+
 // visiting order: counting sort of the targets by their first candidate element
 __global__ __launch_bounds__(256) void gll_key_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn, i64 nelem,
                                                       int2 *__restrict__ key_rank, int *__restrict__ counts)
@@ -569,4 +684,69 @@ extern "C" int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t n
     mm_stage_end(ctx, MM_STAGE_GATHER);
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
+}
+
+// Variant 1 of the GLL acceptance loop (bounding-box pre-test; reference interpolator.py:1409-1473).
+extern "C" int64_t mm_locate_gll_bbox(mm_context *ctx, int order, int dim, int64_t k, int64_t npoints,
+                                      const int64_t *nn_d, const double *gll_points_d, int64_t nelem,
+                                      const double *points_d, int64_t *elem_d, double *coeffs_d)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(order == 1 || order == 2 || order == 4, "order must be 1, 2 or 4");
+    MM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    MM_REQUIRE(k >= 0 && npoints >= 0 && nelem >= 0, "negative size");
+    MM_REQUIRE(k <= MM_KNN_MAX_K, "nelem_to_search must be <= MM_KNN_MAX_K");
+    MM_REQUIRE(npoints == 0 || (elem_d && coeffs_d && points_d), "null array");
+    MM_REQUIRE(npoints == 0 || k == 0 || (nn_d && gll_points_d), "null array");
+    MM_REQUIRE(npoints < (int64_t)0x7fffffff && nelem < (int64_t)0x7ffffff0, "too many targets / elements");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(i64), ctx->stream));
+    if (npoints > 0) {
+        mm_stage_begin(ctx, MM_STAGE_LOCATE);
+        const i64 nbins = nelem + 1;
+        const i64 ntiles = (nbins + 1023) / 1024;
+        int rc = mm_scratch_begin(ctx, mm_round256((size_t)(nelem > 0 ? nelem : 1) * 9 * sizeof(double)) +
+                                           mm_round256((size_t)npoints * sizeof(int2)) +
+                                           mm_round256((size_t)npoints * sizeof(int)) +
+                                           2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
+                                           mm_round256((size_t)ntiles * sizeof(int)) + 4096);
+        if (rc != MM_OK) return rc;
+        double *boxes = (double *)mm_scratch_take(ctx, (size_t)(nelem > 0 ? nelem : 1) * 9 * sizeof(double));
+        MM_REQUIRE(boxes != nullptr, "scratch carve failed");
+        const int *visit = nullptr;
+        if (k > 0 && nelem > 0) {
+            int2 *key_rank = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+            int *ord = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
+            int *counts = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+            int *start = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+            int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
+            MM_REQUIRE(key_rank && ord && counts && start && tile_sums, "scratch carve failed");
+            MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(nbins + 1) * sizeof(int), ctx->stream));
+            const unsigned gp = (unsigned)((npoints + 255) / 256);
+            hipLaunchKernelGGL(gll_key_kernel, dim3(gp), dim3(256), 0, ctx->stream, k, npoints, (const i64 *)nn_d, nelem,
+                               key_rank, counts);
+            rc = mm_exclusive_scan_int(ctx, counts, nbins, start, tile_sums);
+            if (rc != MM_OK) return rc;
+            hipLaunchKernelGGL(gll_order_kernel, dim3(gp), dim3(256), 0, ctx->stream, npoints, key_rank, start, ord);
+            visit = ord;
+        }
+        unsigned long long *nh = (unsigned long long *)ctx->d_counters;
+        const unsigned ge = (unsigned)((nelem + 255) / 256), gt = (unsigned)((npoints + 63) / 64);
+#define MM_GLL_V1_CASE(O, D)                                                                                          \
+    if (order == O && dim == D) {                                                                                     \
+        if (nelem > 0)                                                                                                \
+            hipLaunchKernelGGL((gll_box_kernel<O, D>), dim3(ge), dim3(256), 0, ctx->stream, nelem, gll_points_d, boxes); \
+        hipLaunchKernelGGL((locate_gll_v1_kernel<O, D>), dim3(gt), dim3(64), 0, ctx->stream, k, npoints,             \
+                           (const i64 *)nn_d, gll_points_d, nelem, boxes, points_d, (i64 *)elem_d, coeffs_d, nh, visit); \
+    }
+        MM_GLL_V1_CASE(1, 2) MM_GLL_V1_CASE(1, 3) MM_GLL_V1_CASE(2, 2) MM_GLL_V1_CASE(2, 3) MM_GLL_V1_CASE(4, 2)
+        MM_GLL_V1_CASE(4, 3)
+#undef MM_GLL_V1_CASE
+        mm_stage_end(ctx, MM_STAGE_LOCATE);
+        MM_HIP_CHECK(hipGetLastError());
+    }
+    MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ctx->h_counters[0];
 }

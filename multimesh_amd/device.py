@@ -245,6 +245,24 @@ class Context:
                      "mm_locate_gll")
         return elem, coeffs, int(miss)
 
+    def locate_gll_bbox(self, shape_order, nearest_element_indices, gll_points, points):
+        """The bounding-box variant ``_check_if_inside_element`` (reference interpolator.py:1409-1473)
+        for gll_points f64[E, (order+1)^dim, dim].  Returns (elem int64[N], coeffs f64[N,P], number
+        of points whose final inverse transform failed)."""
+        nn = self.asdevice(nearest_element_indices, np.int64)
+        gp = self.asdevice(gll_points, np.float64)
+        pts = self.asdevice(points, np.float64)
+        nelem, P, dim = gp.shape
+        if P != (shape_order + 1) ** dim or pts.shape[1] != dim:
+            raise ValueError("gll_points must be [nelem, (order+1)^dim, dim] and points [N, dim]")
+        n = pts.shape[0]
+        k = nn.shape[1] if len(nn.shape) == 2 else 0
+        elem = self.empty((n,), np.int64)
+        coeffs = self.empty((n, P), np.float64)
+        hard = check(self.lib.mm_locate_gll_bbox(self.handle, shape_order, dim, k, n, nn.ptr, gp.ptr, nelem, pts.ptr,
+                                                 elem.ptr, coeffs.ptr), "mm_locate_gll_bbox")
+        return elem, coeffs, int(hard)
+
     def gather_elem(self, element_nodal_fields, elem, coeffs, point_major=True):
         """``np.sum(coeffs * field[elem], axis=1)`` (reference interpolator.py:976);
         element_nodal_fields f64[C, E, P] (or [E, P]) -> f64[N, C]."""

@@ -597,6 +597,108 @@ i64 mmo_locate_gll(int order, int dim, i64 k, i64 npoints, const i64 *nn, const 
     return missing;
 }
 
+/* A10, variant 1: _check_if_inside_element + boundary_box_check (reference interpolator.py:1350-1367,
+ * :1409-1473; used by gll_2_exodus :274, gll_2_gll_layered_multi :543 and the helpers :1523, :1572).
+ * Per candidate, in order: axis-aligned bounding box of the control nodes (inclusive); inside ->
+ * inverse transform, skip NaN, accept when every |xi| <= 1.04.  Nothing accepted: take the FIRST
+ * candidate whose box contains the point (their "distance" is 0, np.where(dist == min)[0][0]), or,
+ * if no box does, the candidate whose control-node mean is nearest (first minimum); transform again;
+ * NaN (the reference raises unless ignore_hard_elements) or any |xi| >= 1.04 -> the constant
+ * xi = (0.645, -0.5, 0.22) (:1468-1471; its first `dim` components).  Output: element id and the P
+ * Lagrange coefficients of xi.  PARITY UNPINNED like the rest of the GLL section; our definitions:
+ * the centre is the sequential sum of the P nodes from 0.0 divided by P, distances are compared
+ * squared.  Returns the number of points whose final transform was NaN (the reference's ValueError
+ * cases).  Points without any valid candidate get element -1 and zero coefficients (and count). */
+void mmo_gll_element_boxes(int dim, i64 nelem, i64 P, const double *gll_points, double *boxes)
+{
+    for (i64 e = 0; e < nelem; ++e) {
+        const double *X = gll_points + (size_t)e * P * dim;
+        double *b = boxes + (size_t)e * 3 * dim; /* min[dim], max[dim], centre[dim] */
+        for (int d = 0; d < dim; ++d) {
+            double mn = X[d], mx = X[d], sum = 0.0;
+            for (i64 p = 0; p < P; ++p) {
+                const double v = X[p * dim + d];
+                if (v < mn) mn = v;
+                if (v > mx) mx = v;
+                sum = sum + v;
+            }
+            b[d] = mn;
+            b[dim + d] = mx;
+            b[2 * dim + d] = sum / (double)P;
+        }
+    }
+}
+
+i64 mmo_locate_gll_v1(int order, int dim, i64 k, i64 npoints, const i64 *nn, const double *gll_points, i64 nelem,
+                      const double *points, i64 *elem, double *coeffs)
+{
+    static const double hard_xi[3] = {0.645, -0.5, 0.22};
+    int P = 1;
+    for (int d = 0; d < dim; ++d) P *= order + 1;
+    double *boxes = (double *)malloc(sizeof(double) * (size_t)(nelem > 0 ? nelem : 1) * 3 * dim);
+    mmo_gll_element_boxes(dim, nelem, P, gll_points, boxes);
+    i64 hard = 0;
+    for (i64 i = 0; i < npoints; ++i) {
+        const double *pnt = points + i * dim;
+        i64 first_inside = -1, nearest = -1;
+        double nearest_d2 = INFINITY;
+        int found = 0;
+        double xi[3];
+        for (i64 j = 0; j < k && !found; ++j) {
+            const i64 e = nn[i * k + j];
+            if (e < 0 || e >= nelem) continue;
+            const double *b = boxes + (size_t)e * 3 * dim;
+            int inside = 1;
+            for (int d = 0; d < dim; ++d)
+                if (!(pnt[d] >= b[d] && pnt[d] <= b[dim + d])) inside = 0;
+            if (inside) {
+                if (first_inside < 0) first_inside = j;
+                mmo_gll_inverse_transform(order, dim, pnt, gll_points + (size_t)e * P * dim, xi);
+                int ok = 1;
+                for (int d = 0; d < dim; ++d)
+                    if (!(fabs(xi[d]) <= 1.04)) ok = 0; /* NaN fails the comparison too */
+                if (ok) {
+                    elem[i] = e;
+                    mmo_gll_coefficients(order, dim, xi, coeffs + i * P);
+                    found = 1;
+                }
+            } else {
+                double d2 = 0.0;
+                for (int d = 0; d < dim; ++d) {
+                    const double t = pnt[d] - b[2 * dim + d];
+                    d2 = d2 + t * t;
+                }
+                if (d2 < nearest_d2) {
+                    nearest_d2 = d2;
+                    nearest = j;
+                }
+            }
+        }
+        if (found) continue;
+        const i64 ind = first_inside >= 0 ? first_inside : nearest;
+        if (ind < 0) {
+            elem[i] = -1;
+            for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+            hard += 1;
+            continue;
+        }
+        const i64 e = nn[i * k + ind];
+        mmo_gll_inverse_transform(order, dim, pnt, gll_points + (size_t)e * P * dim, xi);
+        int isnan_any = 0, far = 0;
+        for (int d = 0; d < dim; ++d) {
+            if (xi[d] != xi[d]) isnan_any = 1;
+            if (fabs(xi[d]) >= 1.04) far = 1;
+        }
+        if (isnan_any) hard += 1;
+        if (isnan_any || far)
+            for (int d = 0; d < dim; ++d) xi[d] = hard_xi[d];
+        elem[i] = e;
+        mmo_gll_coefficients(order, dim, xi, coeffs + i * P);
+    }
+    free(boxes);
+    return hard;
+}
+
 /* Element-nodal gather: np.sum(coeffs * field[elem_indices], axis=1) (reference
  * interpolator.py:976); field [ncomp][nelem][P]; element -1 contributes zeros. */
 int mmo_gather_elem(const double *field, i64 nelem, i64 ncomp, const i64 *elem, const double *coeffs, i64 npoints,

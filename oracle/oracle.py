@@ -71,6 +71,8 @@ def lib():
         L.mmo_locate_gll.restype = C.c_int64
         L.mmo_locate_gll.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _f64p, C.c_int64, _f64p,
                                      C.c_double, C.c_int, _i64p, _f64p]
+        L.mmo_locate_gll_v1.restype = C.c_int64
+        L.mmo_locate_gll_v1.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _f64p, C.c_int64, _f64p, _i64p, _f64p]
         L.mmo_gather_elem.restype = C.c_int
         L.mmo_gather_elem.argtypes = [_f64p, C.c_int64, C.c_int64, _i64p, _f64p, C.c_int64, C.c_int64, _f64p,
                                       C.c_int]
@@ -180,6 +182,20 @@ def locate_gll(order, nn, gll_points, points, tolerance=1.05, snap_to_nearest=Fa
     miss = lib().mmo_locate_gll(order, dim, k, n, nn, gll_points, nelem, points, tolerance,
                                 1 if snap_to_nearest else 0, elem, coeffs)
     return elem, coeffs, int(miss)
+
+
+def locate_gll_v1(order, nn, gll_points, points):
+    """Control flow of reference interpolator.py:1409-1473 (bounding-box pre-test variant) ->
+    (elem int64[N], coeffs f64[N,P], number of points whose final transform was NaN)."""
+    nn = np.ascontiguousarray(nn, dtype=np.int64)
+    gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    nelem, P, dim = gll_points.shape
+    n, k = nn.shape
+    elem = np.zeros(n, dtype=np.int64)
+    coeffs = np.zeros((n, P))
+    hard = lib().mmo_locate_gll_v1(order, dim, k, n, nn, gll_points, nelem, points, elem, coeffs)
+    return elem, coeffs, int(hard)
 
 
 def gather_elem(fields, elem, coeffs, point_major=True):

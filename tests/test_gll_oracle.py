@@ -118,3 +118,43 @@ def test_order1_gll_equals_reference_pinned_hex8_path():
     assert np.abs(v_hex - v_gll).max() < 1e-7                               # hex8 Newton stops at 1e-8 * scale
     # both found the element whose 8 corners are the hex8 row's node set
     assert all(set(enc[i]) == set(ca[elem[i]]) for i in range(len(pts)))
+
+
+# ---- variant 1: bounding-box pre-test loop (reference interpolator.py:1409-1473) ---------------------
+def test_bbox_variant_branches():
+    src = synth.gll_mesh(5, 2, seed=4, dim=3)
+    rng = np.random.default_rng(1)
+    inside = rng.uniform(0.05, 0.95, size=(400, 3))
+    far = rng.uniform(1.5, 2.0, size=(50, 3))                  # no bounding box contains these
+    pts = np.concatenate([inside, far])
+    nn, _ = O.knn_ckdtree(src.mean(axis=1), pts, 10)
+    elem, coeffs, hard = O.locate_gll_v1(2, nn, src, pts)
+    # `hard` counts the far points whose final transform fails outright (the reference raises there
+    # unless ignore_hard_elements); either way they get the constant xi below
+    assert 0 <= hard <= 50 and (elem >= 0).all()
+    # accepted points: the element's own basis reproduces the point, coefficients sum to one
+    rec = np.einsum("np,npd->nd", coeffs[:400], src[elem[:400]])
+    assert np.abs(rec - inside).max() < 1e-10
+    assert np.abs(coeffs.sum(axis=1) - 1).max() < 1e-12
+    # far points: nearest control-node mean among the candidates, then the reference's constant xi
+    cen = src.mean(axis=1)
+    d = np.linalg.norm(cen[nn[400:]] - far[:, None, :], axis=2)
+    assert np.array_equal(elem[400:], nn[400:][np.arange(50), d.argmin(axis=1)])
+    const = O.gll_coefficients(2, np.array([0.645, -0.5, 0.22]))
+    assert np.allclose(coeffs[400:], const[None, :], rtol=0, atol=0)
+
+
+def test_bbox_variant_first_inside_box_wins_when_nothing_is_accepted():
+    # a point inside an element's bounding box but outside the (sheared) element and 4 % band:
+    # the first candidate whose box contains it is used with the constant xi
+    src = synth.gll_mesh(3, 1, seed=1, dim=2, jitter=0.0).copy()
+    src[:, :, 0] += 0.8 * src[:, :, 1]                         # shear: boxes overlap, elements do not
+    e = 0
+    lo, hi = src[e].min(axis=0), src[e].max(axis=0)
+    p = np.array([[lo[0] + 0.02 * (hi[0] - lo[0]), hi[1] - 0.02 * (hi[1] - lo[1])]])   # a box corner region
+    nn = np.array([[e]], dtype=np.int64)
+    elem, coeffs, hard = O.locate_gll_v1(1, nn, src, p)
+    xi = O.gll_inverse_transform(1, p[0], src[e])
+    assert np.abs(xi).max() > 1.04                              # not acceptable in element e
+    assert elem[0] == e and hard == 0
+    assert np.array_equal(coeffs[0], O.gll_coefficients(1, np.array([0.645, -0.5])))

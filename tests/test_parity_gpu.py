@@ -412,3 +412,26 @@ def test_fused_pipeline_random_order_and_outside_targets(ctx):
     assert nf == nf_o and nf > 0
     assert np.array_equal(enc.numpy(), enc_o) and np.array_equal(w.numpy(), w_o)
     assert np.array_equal(vals.numpy(), O.gather(fields, enc_o, w_o))
+
+
+# ------------------------------------------------------------------------------- GLL, variant 1
+@pytest.mark.parametrize("order,dim", [(1, 3), (2, 3), (4, 3), (2, 2), (4, 2)])
+def test_gll_bbox_variant_equals_the_oracle(ctx, order, dim):
+    # the bounding-box acceptance loop (reference interpolator.py:1409-1473): targets inside, on the
+    # hull and outside the mesh, so that the accept, first-inside-box, nearest-centre and constant-xi
+    # branches all run; element ids and coefficients bit-equal to the oracle's restatement
+    src = synth.gll_mesh(7 if dim == 3 else 14, order, seed=2, dim=dim)
+    rng = np.random.default_rng(order * 10 + dim)
+    pts = rng.uniform(-0.08, 1.08, size=(6000, dim))
+    nn, _ = O.knn_ckdtree(src.mean(axis=1), pts, 12, workers=-1)
+    elem, coeffs, hard = ctx.locate_gll_bbox(order, nn, src, pts)
+    e_o, c_o, h_o = O.locate_gll_v1(order, nn, src, pts)
+    assert hard == h_o
+    assert np.array_equal(elem.numpy(), e_o)
+    assert np.array_equal(coeffs.numpy(), c_o)
+    inside = ((pts > 0.02) & (pts < 0.98)).all(axis=1)
+    # interior points: the accepted element reproduces the point through its own basis
+    rec = np.einsum("np,npd->nd", c_o[inside], src[e_o[inside]])
+    assert np.abs(rec - pts[inside]).max() < 1e-9
+    outside = ((pts < -0.03) | (pts > 1.03)).any(axis=1)
+    assert outside.sum() > 100 and np.abs(c_o[outside].sum(axis=1) - 1).max() < 1e-12
