@@ -377,6 +377,147 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
     if (lane == 0 && missing_total) atomicAdd(nmissing, missing_total);
 }
 
+// First pass with the control nodes in LDS.  Targets arrive sorted by their first candidate element
+// (~90 per element at cfg5's shape), so the 64 lanes of a wave need one or two elements: those are
+// copied into LDS once per solve (coalesced) and every Newton step reads them from there -- all lanes
+// of an element the same address (broadcast) -- instead of going back to L1/L2 for 3 KB per step.  A
+// wave with more than two distinct elements (thinly populated elements) takes further turns of the
+// stage/solve loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
+template <int ORDER, int DIM>
+__global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
+    i64 k, i64 npoints, const i64 *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
+    const double *__restrict__ points, double tolerance, int snap_to_nearest, i64 *__restrict__ elem,
+    double *__restrict__ coeffs, unsigned long long *__restrict__ nmissing, const int *__restrict__ order,
+    int2 *__restrict__ q_out, int *__restrict__ q_out_count, double *__restrict__ best_state,
+    i64 *__restrict__ best_elem_state)
+{
+    using G = Gll<ORDER, DIM>;
+    constexpr int P = G::P;
+    constexpr int kNodeDoubles = P * DIM;
+    __shared__ int2 s_queue[kGllWaveQueue];
+    __shared__ double s_ctrl[2][kNodeDoubles];
+    const int lane = threadIdx.x;
+    int held = 0;
+    unsigned long long missing_total = 0;
+
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 trips = (npoints + stride - 1) / stride;
+    for (i64 trip = 0; trip < trips; ++trip) {
+        const i64 q = first + trip * stride;
+        const bool active = q < npoints;
+        bool requeue = false, missing = false;
+        i64 i = 0, e = -1;
+        int j = 0;
+        double pnt[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pnt[d] = 0.0;
+        if (active) {
+            i = order ? (i64)order[q] : q;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
+            // first valid candidate
+            while (j < k) {
+                e = nn[i * k + j];
+                if (e >= 0 && e < nelem) break;
+                ++j;
+            }
+        }
+        bool pending = active && j < k;
+        bool found = false;
+        double best_xi[DIM];
+        double best_val = 10e9;
+        i64 best_elem = 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) best_xi[d] = 10e9;
+        while (__any(pending)) {
+            // the (up to) two elements of this turn: the first pending lane's and the first other one
+            const unsigned long long pmask = __ballot(pending);
+            const i64 ea = __shfl(e, __ffsll((long long)pmask) - 1);
+            const unsigned long long omask = __ballot(pending && e != ea);
+            const i64 eb = omask ? __shfl(e, __ffsll((long long)omask) - 1) : ea;
+            for (int t = lane; t < kNodeDoubles; t += 64) {
+                s_ctrl[0][t] = gll_points[ea * (i64)kNodeDoubles + t];
+                s_ctrl[1][t] = gll_points[eb * (i64)kNodeDoubles + t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool mine = pending && (e == ea || e == eb);
+            if (mine) {
+                double xi[DIM];
+                G::inverse_transform(pnt, e == ea ? s_ctrl[0] : s_ctrl[1], xi);
+                bool isnan_any = false;
+                double worst = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    if (xi[d] != xi[d]) isnan_any = true;
+                    if (fabs(xi[d]) > worst) worst = fabs(xi[d]);
+                }
+                if (!isnan_any) {
+                    if (worst < best_val) {
+                        best_val = worst;
+                        best_elem = e;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) best_xi[d] = xi[d];
+                    }
+                    bool inside = true;
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d)
+                        if (!(fabs(xi[d]) < tolerance)) inside = false;
+                    if (inside) {
+                        elem[i] = e;
+                        G::coefficients(xi, coeffs + i * P);
+                        found = true;
+                    }
+                }
+                ++j;
+                pending = false;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane is done with the staged nodes
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (active && !found) {
+            if (j < k) {
+                requeue = true;
+                if (snap_to_nearest) {
+                    best_state[i * (DIM + 1)] = best_val;
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) best_state[i * (DIM + 1) + 1 + d] = best_xi[d];
+                    best_elem_state[i] = best_elem;
+                }
+            } else if (snap_to_nearest) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    double v = best_xi[d];
+                    if (v < -1.02) v = -1.02;
+                    if (v > 1.02) v = 1.02;
+                    best_xi[d] = v;
+                }
+                elem[i] = best_elem;
+                G::coefficients(best_xi, coeffs + i * P);
+            } else {
+                elem[i] = -1;
+                for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                missing = true;
+            }
+        }
+        missing_total += __popcll(__ballot(missing));
+        const unsigned long long vote = __ballot(requeue);
+        if (requeue) s_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
+        held += __popcll(vote);
+        if (held > kGllWaveQueue - 64 || (trip == trips - 1 && held > 0)) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(q_out_count, held);
+            base = __shfl(base, 0);
+            for (int t = lane; t < held; t += 64) q_out[base + t] = s_queue[t];
+            held = 0;
+        }
+    }
+    if (lane == 0 && missing_total) atomicAdd(nmissing, missing_total);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -444,9 +585,15 @@ void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const dou
         i64 grid = full_grid >> (p < 6 ? p : 6);
         if (grid > 16384) grid = 16384;
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
-        hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k,
-                           npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, p == 0 ? order : nullptr, q_in,
-                           p == 0 ? nullptr : counters + p, q_out, counters + p + 1, best_state, best_elem_state);
+        if (p == 0 && k > 0 && nelem > 0)
+            hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
+                               k, npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, order, q_out,
+                               counters + p + 1, best_state, best_elem_state);
+        else
+            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k,
+                               npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, p == 0 ? order : nullptr,
+                               q_in, p == 0 ? nullptr : counters + p, q_out, counters + p + 1, best_state,
+                               best_elem_state);
     }
 }
 
