@@ -1,0 +1,21 @@
+"""kNN stage on a strongly graded cloud (coordinates = uniform^p: density varies by orders of
+magnitude across the domain) -- how far the uniform search grid degrades."""
+import json, sys
+import numpy as np
+sys.path.insert(0, ".")
+from multimesh_amd.device import Context
+
+n = 4_000_000
+rng = np.random.default_rng(0)
+ctx = Context(0)
+ctx.set_profiling(True)
+out = {}
+for power in (1.0, 1.5, 2.0, 3.0):
+    src, tgt = rng.uniform(size=(n, 3)) ** power, rng.uniform(size=(n, 3)) ** power
+    d_src, d_tgt = ctx.to_device(src), ctx.to_device(tgt)
+    tree = ctx.knn_build(d_src)
+    for _ in range(2):
+        idx = tree.query(d_tgt, 20)
+        t = ctx.last_timings()
+    out[f"power_{power}"] = {"knn_query_ms": round(t["knn_query"], 2), "fast_kernel_ms": round(t["knn_cell"], 2)}
+print(json.dumps(out))
