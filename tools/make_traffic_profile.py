@@ -9,7 +9,7 @@ kernels whose reads are not 16-byte-per-lane streams; raw_bytes_per_launch = (FE
 """
 import csv, glob, json, sys, collections
 
-KERNELS = {"knn_cell": "knn_strip_kernel", "centroid": "centroid_kernel", "locate_pass0": "locate_pass_kernel",
+KERNELS = {"knn_cell": "knn_strip_kernel", "centroid": "centroid_", "locate_pass0": "locate_pass_kernel",
            "gather": "gather8_kernel", "locate_long_pass": "Li50E"}
 
 
