@@ -798,7 +798,9 @@ __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 ns
         for (int j0 = 0; j0 < nmax; j0 += U) {
             double dj[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[min(j0 + u, CAP - 1)][tg] : INFINITY;
+            // (entries at or beyond the capacity do not exist: an overflowing list is handed over, and
+            // counting its clamped last entry more than once would push ranks past the row)
+            for (int u = 0; u < U; ++u) dj[u] = j0 + u < min(n, CAP) ? s_bd[min(j0 + u, CAP - 1)][tg] : INFINITY;
 #pragma unroll
             for (int o = 0; o < MAXE; ++o) {
                 if (o < owned) {
@@ -1306,7 +1308,9 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         for (int j0 = 0; j0 < nmax; j0 += U) {
             double dj[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) dj[u] = j0 + u < n ? s_bd[tg][min(j0 + u, CAP - 1)] : INFINITY;
+            // (entries at or beyond the capacity do not exist: an overflowing list is handed over, and
+            // counting its clamped last entry more than once would push ranks past the row)
+            for (int u = 0; u < U; ++u) dj[u] = j0 + u < min(n, CAP) ? s_bd[tg][min(j0 + u, CAP - 1)] : INFINITY;
 #pragma unroll
             for (int o = 0; o < MAXE; ++o) {
                 if (o < owned) {

@@ -435,3 +435,24 @@ def test_gll_bbox_variant_equals_the_oracle(ctx, order, dim):
     assert np.abs(rec - pts[inside]).max() < 1e-9
     outside = ((pts < -0.03) | (pts > 1.03)).any(axis=1)
     assert outside.sum() > 100 and np.abs(c_o[outside].sum(axis=1) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("k", [1, 2, 24, 25])
+def test_knn_list_capacities_that_are_not_a_multiple_of_four(ctx, k):
+    # K = 1, 2 and 25 give list capacities of 9, 10 and 37: the last batch of four of the rank loop
+    # reaches past them.  On a strongly anisotropic lattice the isotropic density estimate is poor,
+    # many targets collect more candidates than the capacity (they are handed over), and their
+    # clamped reads once pushed ranks past the row -- into the neighbouring target's ids (found by
+    # tools/fuzz_pipeline.py, seed 424242 case 615).  Dense targets: several rounds per strip.
+    pa, ca = synth.hex_mesh(29, seed=766496109, jitter=0.104)
+    pa = pa * np.array([0.238, 4.876, 4.723])               # plate-like elements, 20 : 1
+    pa[:, 0] += 0.0276 * pa[:, 1]
+    pa += np.array([-563.96, 979.72, -667.06])
+    cen = O.centroid(ca, pa)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(pa.min(axis=0), pa.max(axis=0), size=(60_000, 3))
+    tree = ctx.knn_build(cen)
+    ref, _ = O.knn_ckdtree(cen, q, k, workers=-1)
+    ref = ref.reshape(len(q), k)
+    for _ in range(3):
+        assert np.array_equal(tree.query(q, k).numpy().reshape(len(q), k), ref)

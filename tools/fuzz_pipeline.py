@@ -10,6 +10,7 @@ from multimesh_amd.device import Context
 from oracle import oracle as O
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # replay one case of a seed's sequence
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = Context(0)
 t_start = time.time()
@@ -35,6 +36,8 @@ for case in range(ncases):
     ncomp = int(rng.choice([1, 1, 2, 3, 5]))
     fields = rng.normal(size=(ncomp, len(pa)))
     lazy = bool(rng.random() < 0.7)
+    if only >= 0 and case != only:
+        continue
     ctx.set_lazy_lists(lazy)
     vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=k, want_operator=True)
     vals2, nf2 = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=k)
@@ -52,5 +55,30 @@ for case in range(ncases):
     print(f"case {case:3d} n={n:2d} N={npts:6d} k={k:2d} C={ncomp} lazy={int(lazy)} margin={margin} "
           f"nfailed={nf:6d} fallback={(status >= k).sum():5d} -> {'ok' if good else 'MISMATCH'}", flush=True)
     if not good:
+        e, ww, v1, v2 = enc.numpy(), w.numpy(), vals.numpy(), vals2.numpy()
+        print("  nfailed gpu/oracle/values-only:", nf, nf_o, nf2)
+        bad_e = np.nonzero((e[ok] != enc_o[ok]).any(axis=1))[0]
+        bad_w = np.nonzero((ww[ok] != w_o[ok]).any(axis=1))[0]
+        print("  rows with different ids:", len(bad_e), "weights:", len(bad_w), "failed rows non-zero:",
+              int(e[~ok].any(axis=1).sum()), int(ww[~ok].any(axis=1).sum()))
+        bv1 = np.nonzero((v1.view(np.int64) != ref_vals.view(np.int64)).any(axis=1))[0]
+        bv2 = np.nonzero((v2.view(np.int64) != ref_vals.view(np.int64)).any(axis=1))[0]
+        print("  value rows differing (operator call / values-only call):", len(bv1), len(bv2))
+        for r in list(bv1[:5]) + list(bv2[:5]):
+            print("   row", r, "status", status[r], "gpu", v1[r], v2[r], "ref", ref_vals[r])
+        # is it the kNN stage?  (public int64 lists against cKDTree, three runs: a race shows as varying counts)
+        cen = O.centroid(ca, pa)
+        tree = ctx.knn_build(cen)
+        for rep in range(3):
+            got = tree.query(pb, k).numpy().reshape(npts, k)
+            badr = np.nonzero((got != nn).any(axis=1))[0]
+            print("   kNN run", rep, "rows differing from cKDTree:", len(badr))
+            for r in badr[:3]:
+                pos = np.nonzero(got[r] != nn[r])[0]
+                print("     row", r, "differs at", pos, "ours", got[r][pos], "ref", nn[r][pos], "same set", set(got[r]) == set(nn[r]))
+        idx_ok = np.nonzero(ok)[0]
+        for r in bad_e[:5]:
+            t = idx_ok[r]
+            print("   target", t, "status", status[t], "gpu ids", e[t], "ref ids", enc_o[t])
         sys.exit(1)
 print(f"{ncases} cases ok in {time.time() - t_start:.0f} s")
