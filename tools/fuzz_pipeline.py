@@ -31,7 +31,7 @@ for case in range(ncases):
     if rng.random() < 0.3:                                   # some targets exactly on mesh nodes
         take = rng.integers(0, len(pa), size=min(npts, 500))
         pb[: len(take)] = pa[take]
-    k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 20, 25, 32]))
+    k = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 13, 16, 20, 24, 25, 32, 33, 40, 64]))
     k = min(k, len(ca))
     ncomp = int(rng.choice([1, 1, 2, 3, 5]))
     fields = rng.normal(size=(ncomp, len(pa)))
