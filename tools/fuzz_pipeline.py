@@ -11,11 +11,12 @@ from oracle import oracle as O
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # replay one case of a seed's sequence
+big = len(sys.argv) > 4 and sys.argv[4] == "big"         # meshes up to 120^3 nodes, up to 2 M targets
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = Context(0)
 t_start = time.time()
 for case in range(ncases):
-    n = int(rng.integers(4, 42))
+    n = int(rng.integers(60, 121)) if big else int(rng.integers(4, 42))
     pa, ca = synth.hex_mesh(n, seed=int(rng.integers(1, 1 << 30)), jitter=float(rng.uniform(0.0, 0.3)) + 1e-3)
     pa = pa.copy()
     if rng.random() < 0.5:                                   # anisotropy / shear / offset
@@ -25,7 +26,7 @@ for case in range(ncases):
     # general position (no exact kNN ties): a tiny random perturbation of every node
     pa += rng.normal(scale=1e-9 * np.ptp(pa, axis=0).max(), size=pa.shape)
     lo, hi = pa.min(axis=0), pa.max(axis=0)
-    npts = int(rng.integers(1, 60_000))
+    npts = int(rng.integers(200_000, 2_000_000)) if big else int(rng.integers(1, 60_000))
     margin = rng.choice([0.0, 0.02, 0.3])
     pb = rng.uniform(lo - margin * (hi - lo), hi + margin * (hi - lo), size=(npts, 3))
     if rng.random() < 0.3:                                   # some targets exactly on mesh nodes
