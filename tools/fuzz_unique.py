@@ -1,0 +1,32 @@
+"""Randomised check of mm_unique_points against np.unique(axis=0, return_inverse=True)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from multimesh_amd.device import Context
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+ctx = Context(0)
+t0 = time.time()
+for case in range(ncases):
+    dim = int(rng.integers(1, 4))
+    n = int(rng.choice([rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 1_500_000)]))
+    kind = rng.choice(["floats", "few_values", "lattice", "signed"])
+    if kind == "floats":
+        base = rng.normal(size=(max(1, n // int(rng.integers(1, 6))), dim))
+        pts = base[rng.integers(0, len(base), size=n)]
+    elif kind == "few_values":
+        pts = rng.integers(-3, 4, size=(n, dim)).astype(np.float64)
+    elif kind == "lattice":
+        pts = np.round(rng.uniform(-5, 5, size=(n, dim)), int(rng.integers(0, 3)))
+    else:
+        pts = rng.integers(-2, 3, size=(n, dim)).astype(np.float64) * rng.choice([1.0, -0.0, 1e-300, 1e300], size=(n, dim))
+    pts = np.ascontiguousarray(pts)
+    u, inv = ctx.unique_points(pts)
+    u, inv = u.numpy(), inv.numpy()
+    ru, rinv = np.unique(pts, axis=0, return_inverse=True)
+    good = u.shape == ru.shape and np.array_equal(u, ru) and np.array_equal(inv, rinv.reshape(-1)) and np.array_equal(u[inv], pts)
+    print(f"case {case:3d} dim={dim} n={n:7d} {kind:10s} unique={len(ru):7d} -> {'ok' if good else 'MISMATCH'}", flush=True)
+    if not good:
+        sys.exit(1)
+print(f"{ncases} cases ok in {time.time() - t0:.0f} s")
