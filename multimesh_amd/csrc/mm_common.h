@@ -67,6 +67,7 @@ struct mm_context {
     hipEvent_t ev_end[MM_STAGE_COUNT];
     bool ev_used[MM_STAGE_COUNT];
     bool ev_created = false;
+    hipEvent_t ev_misc = nullptr;   // host waits on small readbacks while later work stays queued
 };
 
 // Reserve `total` bytes of scratch for the current call (may reallocate), then carve with

@@ -50,9 +50,11 @@ extern "C" int mm_context_create(int device, void *hip_stream, mm_context **out)
     ctx->stream = (hipStream_t)hip_stream;
     hipError_t e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(i64));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(i64), 0);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_misc, hipEventDisableTiming);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         delete ctx;
         return MM_ERR_HIP;
     }
@@ -71,6 +73,7 @@ extern "C" void mm_context_destroy(mm_context *ctx)
         if (ctx->buf_ptr[s]) (void)hipFree(ctx->buf_ptr[s]);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev_misc) (void)hipEventDestroy(ctx->ev_misc);
     if (ctx->ev_created)
         for (int s = 0; s < MM_STAGE_COUNT; ++s) {
             (void)hipEventDestroy(ctx->ev_begin[s]);

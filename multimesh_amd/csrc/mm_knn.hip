@@ -30,6 +30,14 @@ namespace {
 constexpr int kBlock = 256;
 constexpr double kDefaultPerCell = 8.0;  // average sources per cell: the k = 20 ball (radius ~0.84 cell) fits the 3x3x3 block
 constexpr int kMaxCellsPerAxis = 1024;
+// adaptive grid (mm_knn_build_impl): a cell is overfull above kOverfullCount sources; when more than
+// kRefineShare of the sources sit in overfull cells the grid is laid out again with 8x the cells
+constexpr int kOverfullCount = 24;
+constexpr double kRefineShare = 0.25;
+constexpr int kMaxRefine = 1;   // a second level costs more on the sparse side than it saves
+constexpr i64 kRefineMinSources = 4096;
+constexpr double kRefineMaxCellsPerSource = 8.0;
+constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
 
 struct GridParams {
     int nx, ny, nz;
@@ -103,6 +111,17 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
     double t = (x - lo) * ih;
     t = fmin(fmax(t, 0.0), (double)(n - 1));  // NaN -> 0, outside -> clamped
     return (int)t;
+}
+
+// Sum of the counts of the cells holding more than kOverfullCount sources (adaptive grid statistic).
+__global__ __launch_bounds__(kBlock) void overfull_share_kernel(const int *__restrict__ counts, i64 ncells,
+                                                                unsigned long long *__restrict__ total)
+{
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = c < ncells ? counts[c] : 0;
+    if (v <= kOverfullCount) v = 0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicAdd(total, (unsigned long long)v);
 }
 
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
@@ -1538,6 +1557,11 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         const double v = atof(env);
         if (v >= 0.25 && v <= 4096.0) per_cell = v;
     }
+    int max_refine = kMaxRefine;
+    if (const char *env = getenv("MM_KNN_REFINE")) max_refine = atoi(env) < 0 ? 0 : (atoi(env) > 3 ? 3 : atoi(env));
+    double refine_share = kRefineShare, refine_cells = kRefineMaxCellsPerSource;
+    if (const char *env = getenv("MM_KNN_REFINE_SHARE")) refine_share = atof(env);
+    if (const char *env = getenv("MM_KNN_REFINE_CELLS")) refine_cells = atof(env);
     double ext[3] = {0, 0, 0};
     int live = 0;
     double vol = 1.0;
@@ -1549,6 +1573,14 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
             vol *= ext[a];
         }
     }
+    // A graded cloud (mesh refined towards a surface or a source region) puts most of its points
+    // into a few overfull cells of a grid sized for the mean density, and those cells fall off the
+    // tiled kernels.  The build therefore measures the share of sources in overfull cells and, when
+    // it is large, lays the grid out again with cells of half the edge -- sized for where the
+    // points are; the sparse remainder is what the ring-expansion kernel is for.  The statistic is
+    // read back while the scan and the scatter of the same attempt are still queued, so a uniform
+    // cloud pays no idle time for it.
+    for (int attempt = 0;; ++attempt) {
     const double want_cells = nsrc > 0 ? (double)nsrc / per_cell : 1.0;
     const double edge = live > 0 ? pow(vol / (want_cells > 1.0 ? want_cells : 1.0), 1.0 / live) : 1.0;
     i64 ncells = 1;
@@ -1568,6 +1600,13 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     const GridParams g = params_of(ix);
 
     hipError_t e = hipSuccess;
+    if (attempt > 0 && !use_context_buffers) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ix->cell_start) (void)hipFree(ix->cell_start);
+        if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
+        ix->cell_start = nullptr;
+        ix->sorted_xyz = nullptr;
+    }
     if (use_context_buffers) {
         ix->borrowed = true;
         int brc = mm_buffer_get(ctx, MM_BUF_CELL_START, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
@@ -1608,6 +1647,23 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     if (nsrc > 0)
         hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim, g,
                            cell_of, counts);
+    const bool may_refine = attempt < max_refine && nsrc >= kRefineMinSources && live > 0 &&
+                            (double)ncells * 8.0 <= refine_cells * (double)nsrc;
+    if (may_refine) {
+        i64 *stat = ctx->d_counters + kStatSlot;
+        e = hipMemsetAsync(stat, 0, sizeof(i64), ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(overfull_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                               ctx->stream, counts, ncells, (unsigned long long *)stat);
+            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
+            free_index(ix);
+            return MM_ERR_HIP;
+        }
+    }
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
@@ -1620,6 +1676,21 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         mm_set_error(MM_ERR_HIP, "kNN build launch: %s", hipGetErrorString(e));
         free_index(ix);
         return MM_ERR_HIP;
+    }
+    if (!may_refine) break;
+    e = hipEventSynchronize(ctx->ev_misc);
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
+        free_index(ix);
+        return MM_ERR_HIP;
+    }
+    const i64 overfull = ctx->h_counters[kStatSlot];
+    if (getenv("MM_KNN_DEBUG"))
+        fprintf(stderr, "[mm_knn] build attempt %d: %lld cells, %.1f %% of the sources in overfull cells\n", attempt,
+                (long long)ncells, 100.0 * (double)overfull / (double)nsrc);
+    if ((double)overfull <= refine_share * (double)nsrc) break;
+    per_cell *= 0.125;
+    if (getenv("MM_KNN_DEBUG")) fprintf(stderr, "[mm_knn] laying the grid out again at %.3g sources per cell\n", per_cell);
     }
     *out = ix;
     return MM_OK;

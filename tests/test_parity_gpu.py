@@ -456,3 +456,21 @@ def test_knn_list_capacities_that_are_not_a_multiple_of_four(ctx, k):
     ref = ref.reshape(len(q), k)
     for _ in range(3):
         assert np.array_equal(tree.query(q, k).numpy().reshape(len(q), k), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("power", [2.0, 3.0])
+def test_knn_graded_cloud_relaid_grid(ctx, power, monkeypatch):
+    # coordinates = uniform^p: most sources sit in a few cells of a grid sized for the mean density,
+    # so the build lays the grid out a second time with finer cells (mm_knn.hip, "adaptive grid").
+    # Same lists from the relaid grid, from the plain one and from the k-d tree.
+    rng = np.random.default_rng(17)
+    src = rng.uniform(size=(150_000, 3)) ** power
+    q = rng.uniform(size=(40_000, 3)) ** power
+    ref, dref = O.knn_ckdtree(src, q, 20, workers=-1)
+    for refine in ("1", "0"):
+        monkeypatch.setenv("MM_KNN_REFINE", refine)
+        tree = ctx.knn_build(src)
+        idx, dist = tree.query(q, 20, want_dist=True)
+        assert np.array_equal(idx.numpy().reshape(len(q), 20), ref.reshape(len(q), 20))
+        np.testing.assert_allclose(dist.numpy().reshape(len(q), 20), dref.reshape(len(q), 20), rtol=1e-12, atol=0)
