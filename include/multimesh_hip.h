@@ -156,6 +156,22 @@ int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64
                    const int64_t *elem_d, const double *coeffs_d, int64_t npoints, int64_t P, double *out_d,
                    int out_point_major);
 
+/* The GLL form of the whole path on resident arrays: what reference components/interpolator.py:931-977
+ * (interpolate_to_points on a GLL mesh) and the core of gll_2_gll (:700-830) compute for an array
+ * of points -- centroid of every element's control nodes (NumPy mean(axis=1) order,
+ * salvus_mesh_reader.py:99-100), the nelem_to_search nearest centroids, the acceptance loop of
+ * :1181-1233 (mm_locate_gll), then np.sum(coeffs * field[elem], axis=1) per component (:976).
+ *   gll_points_d f64[nelem][P][dim], points_d f64[npoints][dim], fields_d f64[ncomp][nelem][P],
+ *   out_d f64[npoints][ncomp]; points that are not found give +-0.0 like NumPy's field[-1] * 0.
+ *   elem_out_d int64[npoints] and coeffs_out_d f64[npoints][P]: both or neither (the operator).
+ * Without the operator outputs the sum is formed where a target is accepted (no coefficient array
+ * in memory), and the candidate lists are evaluated lazily (mm_set_lazy_lists); results are
+ * identical to the staged calls.  Returns the number of points not found, or a negative MM_ERR_*. */
+int64_t mm_interpolate_gll(mm_context *ctx, int order, int dim, const double *gll_points_d, int64_t nelem,
+                           const double *points_d, int64_t npoints, const double *fields_d, int64_t ncomp,
+                           int64_t nelem_to_search, double tolerance, int snap_to_nearest, double *out_d,
+                           int64_t *elem_out_d, double *coeffs_out_d);
+
 /* Unique points and the index array that rebuilds the input: np.unique(points, axis=0,
  * return_inverse=True) of reference utils.py:484-488 (get_unique_points, the pre-step of the GLL
  * target flows; scatter-back at components/interpolator.py:823).  points_d f64[npoints][dim];

@@ -203,14 +203,13 @@ def interpolate_gll_to_points(mesh: GllMesh, points, params_to_interp, nelem_to_
     element weights, then ``np.sum(coeffs * field[elem], axis=1)`` per parameter -> f64[N, C]."""
     ctx = context or default_context()
     points = np.ascontiguousarray(points, dtype=np.float64)
-    tree = ctx.knn_build(mesh.get_element_centroid())
-    nn = tree.query(points, nelem_to_search)
-    elem, coeffs, num_failed = ctx.locate_gll(mesh.shape_order, nn, mesh.gll_points, points, tolerance, False)
+    fields = np.stack([mesh.element_nodal_fields[p] for p in params_to_interp])
+    vals, num_failed = ctx.interpolate_gll(mesh.shape_order, mesh.gll_points, points, fields,
+                                           nelem_to_search=nelem_to_search, tolerance=tolerance)
     if num_failed > 0:
         print(num_failed, "points could not find an enclosing element. These points will be set to zero. "
                           "Please check your domain or the interpolation tuning parameters")
-    fields = np.stack([mesh.element_nodal_fields[p] for p in params_to_interp])
-    return ctx.gather_elem(fields, elem, coeffs).numpy()
+    return vals.numpy()
 
 
 def get_unique_points(points, context=None):
@@ -232,14 +231,13 @@ def interpolate_gll_to_gll(mesh_a: GllMesh, target_gll_points, params_to_interp,
     ctx = context or default_context()
     tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
     uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]))
-    tree = ctx.knn_build(mesh_a.get_element_centroid())
-    nn = tree.query(uniq, nelem_to_search)
-    elem, coeffs, num_failed = ctx.locate_gll(mesh_a.shape_order, nn, mesh_a.gll_points, uniq, tolerance, False)
+    fields = np.stack([mesh_a.element_nodal_fields[p] for p in params_to_interp])
+    vals, num_failed = ctx.interpolate_gll(mesh_a.shape_order, mesh_a.gll_points, uniq, fields,
+                                           nelem_to_search=nelem_to_search, tolerance=tolerance)
     if num_failed > 0:
         print(num_failed, "points could not find an enclosing element. These points will be set to zero. "
                           "Please check your domain or the interpolation tuning parameters")
-    fields = np.stack([mesh_a.element_nodal_fields[p] for p in params_to_interp])
-    vals = ctx.gather_elem(fields, elem, coeffs).numpy()            # [U, C]
+    vals = vals.numpy()                                             # [U, C]
     return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(params_to_interp), tgt.shape[0], tgt.shape[1])
 
 

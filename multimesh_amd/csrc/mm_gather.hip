@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void gather8_kernel(const double *__restrict__
         s = s + dpp_move_f64<DPP_QUAD_XOR1>(s);
         s = s + dpp_move_f64<DPP_QUAD_XOR2>(s);
         if (valid && q == 0) {
-            if (POINT_MAJOR) out[n * ncomp + c] = s;
-            else out[(i64)c * npoints + n] = s;
+            // NumPy starts a reduction from the identity: 0.0 + (row sum), visible where the sum is -0.0
+            if (POINT_MAJOR) out[n * ncomp + c] = 0.0 + s;
+            else out[(i64)c * npoints + n] = 0.0 + s;
         }
     }
 }
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void gatherP_kernel(const double *__restrict__
             for (int i = 0; i < tail; ++i) res += __shfl(a, group_base + i);
         }
         if (valid && j == 0) {
-            if (POINT_MAJOR) out[n * ncomp + c] = res;
-            else out[(i64)c * npoints + n] = res;
+            if (POINT_MAJOR) out[n * ncomp + c] = 0.0 + res;   // from the identity, as above
+            else out[(i64)c * npoints + n] = 0.0 + res;
         }
     }
 }

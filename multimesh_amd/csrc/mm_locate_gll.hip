@@ -234,7 +234,81 @@ struct Gll {
                 for (int i = 0; i < n; ++i) out[i + n * j] = l[0][i] * l[1][j];
         }
     }
+
+    // sum_p coeff[p] * f[p] in NumPy's row-sum order (np.sum(coeffs * field[elem], axis=1), reference
+    // interpolator.py:976; the order is spelled out in mm_gather.hip), coeff[p] formed exactly as
+    // coefficients() forms it -- or 0.0 for a point that was not found (`zero`).  One lane, all P
+    // terms: the values-only pipeline uses this at the point of acceptance instead of writing the
+    // P coefficients (1 kB per target at order 4) for a gather kernel to read back.
+    static __device__ __forceinline__ double weighted_sum(const double (&l)[DIM][n], bool zero,
+                                                          const double *__restrict__ f)
+    {
+        constexpr int tail = P & 7, nfull = P - tail;
+        double r[8];
+        double res = 0.;
+        constexpr int nk = DIM == 3 ? n : 1;
+#pragma unroll
+        for (int k = 0; k < nk; ++k)
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                // one row of field values at a time (see inverse_transform): hoisting all P loads
+                // to the top of the unrolled loop spills
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    const int p = i + n * (j + n * k);
+                    double c = DIM == 3 ? (l[0][i] * l[1][j]) * l[DIM - 1][k] : l[0][i] * l[1][j];
+                    if (zero) c = 0.0;
+                    const double a = c * f[p];
+                    if (P < 8) {
+                        res += a;
+                    } else if (p < 8) {
+                        r[p] = a;
+                    } else if (p < nfull) {
+                        r[p & 7] += a;
+                    }
+                    if (P >= 8 && p == nfull - 1)
+                        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                    if (P >= 8 && p >= nfull) res += a;
+                }
+            }
+        return 0.0 + res;   // NumPy starts the reduction from the identity (-0.0 reads +0.0)
+    }
 };
+
+// What a located target leaves behind: element id and coefficients (the staged mm_locate_gll), and /
+// or the interpolated values themselves (mm_interpolate_gll without operator outputs).
+struct GllEmit {
+    i64 *elem;             // [N] or null
+    double *coeffs;        // [N][P] or null
+    const double *fields;  // [ncomp][nelem][P] or null
+    double *out;           // [N][ncomp] or null
+    int ncomp;
+};
+
+// found == false: the reference's "-1 and zero coefficients"; NumPy's field[-1] is the LAST element
+template <int ORDER, int DIM>
+__device__ __forceinline__ void gll_emit(const GllEmit &em, i64 i, i64 e, const double (&xi)[DIM], bool found, i64 nelem)
+{
+    using G = Gll<ORDER, DIM>;
+    constexpr int P = G::P;
+    if (em.elem) em.elem[i] = found ? e : -1;
+    if (em.coeffs) {
+        if (found) G::coefficients(xi, em.coeffs + i * P);
+        else
+            for (int p = 0; p < P; ++p) em.coeffs[i * P + p] = 0.0;
+    }
+    if (em.out) {
+        double g[G::n];
+        gll_nodes<ORDER>(g);
+        double l[DIM][G::n], dl[DIM][G::n];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) lagrange_1d<ORDER>(g, found ? xi[d] : 0.0, l[d], dl[d]);
+        const i64 ef = found ? e : nelem - 1;
+        for (int c = 0; c < em.ncomp; ++c)
+            em.out[i * em.ncomp + c] = G::weighted_sum(l, !found, em.fields + ((i64)c * nelem + ef) * P);
+    }
+}
 
 // Control flow of reference interpolator.py:1181-1233 (see the oracle's mmo_locate_gll), scheduled
 // as COMPACTING PASSES like the hex8 locate: a pass performs at most one inverse transform per
@@ -244,13 +318,14 @@ struct Gll {
 // queue.  With snap_to_nearest the least-outside candidate seen so far travels in per-target state
 // arrays.  Re-queue entries are batched per wave in LDS (one global atomic per ~200 entries).
 constexpr int kGllWaveQueue = 256;
+constexpr int kGllLazyK = 8;   // candidates asked of the kNN stage up front by mm_interpolate_gll
 
-template <int ORDER, int DIM>
-__global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+template <int ORDER, int DIM, typename IDX>
+__global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
+                                                             const IDX *__restrict__ nn,
                                                              const double *__restrict__ gll_points, i64 nelem,
                                                              const double *__restrict__ points, double tolerance,
-                                                             int snap_to_nearest, i64 *__restrict__ elem,
-                                                             double *__restrict__ coeffs,
+                                                             int snap_to_nearest, GllEmit em,
                                                              unsigned long long *__restrict__ nmissing,
                                                              const int *__restrict__ order,
                                                              const int2 *__restrict__ q_in,
@@ -299,15 +374,15 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
                 for (int d = 0; d < DIM; ++d) best_xi[d] = best_state[i * (DIM + 1) + 1 + d];
                 best_elem = best_elem_state[i];
             }
-            // next valid candidate
-            while (j < k) {
-                const i64 e = nn[i * k + j];
+            // next valid candidate; this array holds the first kavail <= k of the target's list
+            while (j < kavail) {
+                const i64 e = (i64)nn[i * kavail + j];
                 if (e >= 0 && e < nelem) break;
                 ++j;
             }
             bool found = false;
-            if (j < k) {
-                const i64 e = nn[i * k + j];
+            if (j < kavail) {
+                const i64 e = (i64)nn[i * kavail + j];
                 double xi[DIM];
                 G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
                 bool isnan_any = false;
@@ -329,8 +404,7 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
                     for (int d = 0; d < DIM; ++d)
                         if (!(fabs(xi[d]) < tolerance)) inside = false;
                     if (inside) {
-                        elem[i] = e;
-                        G::coefficients(xi, coeffs + i * P);
+                        gll_emit<ORDER, DIM>(em, i, e, xi, true, nelem);
                         found = true;
                     }
                 }
@@ -338,7 +412,7 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
             }
             if (!found) {
                 if (j < k) {
-                    requeue = true;
+                    requeue = true;   // also: the short list is used up and the full one is needed
                     if (snap_to_nearest) {
                         best_state[i * (DIM + 1)] = best_val;
 #pragma unroll
@@ -353,11 +427,9 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
                         if (v > 1.02) v = 1.02;
                         best_xi[d] = v;
                     }
-                    elem[i] = best_elem;
-                    G::coefficients(best_xi, coeffs + i * P);
+                    gll_emit<ORDER, DIM>(em, i, best_elem, best_xi, true, nelem);
                 } else {
-                    elem[i] = -1;
-                    for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                    gll_emit<ORDER, DIM>(em, i, 0, best_xi, false, nelem);
                     missing = true;
                 }
             }
@@ -383,11 +455,11 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, i64 npoin
 // of an element the same address (broadcast) -- instead of going back to L1/L2 for 3 KB per step.  A
 // wave with more than two distinct elements (thinly populated elements) takes further turns of the
 // stage/solve loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
-template <int ORDER, int DIM>
+template <int ORDER, int DIM, typename IDX>
 __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
-    i64 k, i64 npoints, const i64 *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
-    const double *__restrict__ points, double tolerance, int snap_to_nearest, i64 *__restrict__ elem,
-    double *__restrict__ coeffs, unsigned long long *__restrict__ nmissing, const int *__restrict__ order,
+    i64 k, int kavail, i64 npoints, const IDX *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
+    const double *__restrict__ points, double tolerance, int snap_to_nearest, GllEmit em,
+    unsigned long long *__restrict__ nmissing, const int *__restrict__ order,
     int2 *__restrict__ q_out, int *__restrict__ q_out_count, double *__restrict__ best_state,
     i64 *__restrict__ best_elem_state)
 {
@@ -417,13 +489,13 @@ __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
 #pragma unroll
             for (int d = 0; d < DIM; ++d) pnt[d] = points[i * DIM + d];
             // first valid candidate
-            while (j < k) {
-                e = nn[i * k + j];
+            while (j < kavail) {
+                e = (i64)nn[i * kavail + j];
                 if (e >= 0 && e < nelem) break;
                 ++j;
             }
         }
-        bool pending = active && j < k;
+        bool pending = active && j < kavail;
         bool found = false;
         double best_xi[DIM];
         double best_val = 10e9;
@@ -466,8 +538,7 @@ __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
                     for (int d = 0; d < DIM; ++d)
                         if (!(fabs(xi[d]) < tolerance)) inside = false;
                     if (inside) {
-                        elem[i] = e;
-                        G::coefficients(xi, coeffs + i * P);
+                        gll_emit<ORDER, DIM>(em, i, e, xi, true, nelem);
                         found = true;
                     }
                 }
@@ -495,11 +566,9 @@ __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
                     if (v > 1.02) v = 1.02;
                     best_xi[d] = v;
                 }
-                elem[i] = best_elem;
-                G::coefficients(best_xi, coeffs + i * P);
+                gll_emit<ORDER, DIM>(em, i, best_elem, best_xi, true, nelem);
             } else {
-                elem[i] = -1;
-                for (int p = 0; p < P; ++p) coeffs[i * P + p] = 0.0;
+                gll_emit<ORDER, DIM>(em, i, 0, best_xi, false, nelem);
                 missing = true;
             }
         }
@@ -543,7 +612,9 @@ __global__ __launch_bounds__(256) void gather_elem_kernel(const double *__restri
     const bool valid = n_raw < npoints;
     const i64 n = valid ? n_raw : npoints - 1;
     const i64 e_raw = elem[n];
-    const i64 e = (unsigned long long)e_raw < (unsigned long long)nelem ? e_raw : 0;  // -1 (not found): zeros
+    // -1 (not found, zero coefficients) reads the LAST element like NumPy's field[-1]: the sign of the zero
+    const i64 e = (unsigned long long)e_raw < (unsigned long long)nelem ? e_raw
+                  : (e_raw < 0 && e_raw >= -nelem ? e_raw + nelem : 0);
     const double *crow = coeffs + n * P;
     const int tail = P & 7;
     const int nfull = P - tail;
@@ -565,16 +636,35 @@ __global__ __launch_bounds__(256) void gather_elem_kernel(const double *__restri
             for (int i = 0; i < tail; ++i) res += __shfl(a, group_base + i);
         }
         if (valid && j == 0) {
-            if (POINT_MAJOR) out[n * ncomp + c] = res;
-            else out[(i64)c * npoints + n] = res;
+            // NumPy starts a reduction from the identity: 0.0 + (row sum), visible where the sum is -0.0
+            if (POINT_MAJOR) out[n * ncomp + c] = 0.0 + res;
+            else out[(i64)c * npoints + n] = 0.0 + res;
         }
     }
 }
 
-template <int ORDER, int DIM>
-void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const double *gll, i64 nelem,
-                   const double *pts, double tol, int snap, i64 *elem, double *coeffs, unsigned long long *nmiss,
-                   const int *order, int2 *qa, int2 *qb, int *counters, double *best_state, i64 *best_elem_state)
+// Lazily evaluated candidate lists (fused pipeline): nn holds only the kavail nearest; after kavail
+// passes the still-open targets get their full lists from the generic kNN kernel (list mode) and
+// the remaining passes read those.  The k' nearest are the first k' of the k nearest, so results
+// do not depend on it.
+struct GllLazy {
+    const mm_knn_index *index;
+    int *nn_full;   // [N][k], rows filled on demand
+};
+
+__global__ __launch_bounds__(256) void gll_queue_ids_kernel(const int2 *__restrict__ q, const int *__restrict__ q_count,
+                                                            int *__restrict__ list)
+{
+    const i64 total = *q_count;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) list[t] = q[t].x;
+}
+
+template <int ORDER, int DIM, typename IDX>
+int launch_locate(mm_context *ctx, i64 k, int kavail, i64 npoints, const IDX *nn, const double *gll, i64 nelem,
+                  const double *pts, double tol, int snap, const GllEmit &em, unsigned long long *nmiss,
+                  const int *order, int2 *qa, int2 *qb, int *counters, double *best_state, i64 *best_elem_state,
+                  const GllLazy *lazy, int *id_list)
 {
     const i64 full_grid = (npoints + 63) / 64;
     const i64 npasses = k > 0 ? k : 1;
@@ -585,16 +675,29 @@ void launch_locate(mm_context *ctx, i64 k, i64 npoints, const i64 *nn, const dou
         i64 grid = full_grid >> (p < 6 ? p : 6);
         if (grid > 16384) grid = 16384;
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
-        if (p == 0 && k > 0 && nelem > 0)
-            hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
-                               k, npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, order, q_out,
+        const bool full_lists = lazy && p >= kavail;
+        if (lazy && p == kavail) {
+            hipLaunchKernelGGL(gll_queue_ids_kernel, dim3(64), dim3(256), 0, ctx->stream, q_in, counters + p, id_list);
+            int rc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, k, lazy->nn_full, id_list, counters + p);
+            if (rc != MM_OK) return rc;
+        }
+        if (p == 0 && k > 0 && nelem > 0) {
+            hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0,
+                               ctx->stream, k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, order, q_out,
                                counters + p + 1, best_state, best_elem_state);
-        else
-            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, k,
-                               npoints, nn, gll, nelem, pts, tol, snap, elem, coeffs, nmiss, p == 0 ? order : nullptr,
+        } else if (full_lists) {
+            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, int>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
+                               k, (int)k, npoints, (const int *)lazy->nn_full, gll, nelem, pts, tol, snap, em, nmiss,
+                               (const int *)nullptr, q_in, counters + p, q_out, counters + p + 1, best_state,
+                               best_elem_state);
+        } else {
+            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
+                               k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, p == 0 ? order : nullptr,
                                q_in, p == 0 ? nullptr : counters + p, q_out, counters + p + 1, best_state,
                                best_elem_state);
+        }
     }
+    return MM_OK;
 }
 
 // ---- variant 1 (reference interpolator.py:1350-1367, :1409-1473; oracle mmo_locate_gll_v1) ----------
@@ -713,12 +816,13 @@ __global__ __launch_bounds__(64, 3) void locate_gll_v1_kernel(i64 k, i64 npoints
 }
 
 // visiting order: counting sort of the targets by their first candidate element
-__global__ __launch_bounds__(256) void gll_key_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn, i64 nelem,
+template <typename IDX>
+__global__ __launch_bounds__(256) void gll_key_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn, i64 nelem,
                                                       int2 *__restrict__ key_rank, int *__restrict__ counts)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npoints) return;
-    const i64 e = nn[t * k];
+    const i64 e = (i64)nn[t * k];
     const int key = (unsigned long long)e < (unsigned long long)nelem ? (int)e : (int)nelem;  // invalid -> last bin
     key_rank[t] = make_int2(key, atomicAdd(&counts[key], 1));
 }
@@ -735,6 +839,68 @@ __global__ __launch_bounds__(256) void gll_order_kernel(i64 npoints, const int2 
 }  // namespace
 
 int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums);
+int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks);
+int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
+                      double *dist_d, bool idx_is_int32);
+
+// The locate stage on ctx->stream: visiting order, passes, no synchronisation.  nn holds the first
+// kavail (<= k) candidates of every target (kavail < k only with `lazy`).  The number of targets
+// that were not found is added to ctx->d_counters[0].
+template <typename IDX>
+static int locate_gll_run(mm_context *ctx, int order, int dim, i64 k, int kavail, i64 npoints, const IDX *nn,
+                          const double *gll_points_d, i64 nelem, const double *points_d, double tolerance,
+                          int snap_to_nearest, const GllEmit &em, const GllLazy *lazy)
+{
+    unsigned long long *nm = (unsigned long long *)ctx->d_counters;
+    // scratch: visiting order, two pass queues, their counters, snap state
+    const int *visit = nullptr;
+    const i64 nbins = nelem + 1;
+    const i64 ntiles = (nbins + 1023) / 1024;
+    int rc = mm_scratch_begin(ctx, 3 * mm_round256((size_t)npoints * sizeof(int2)) +
+                                       2 * mm_round256((size_t)npoints * sizeof(int)) +
+                                       2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
+                                       mm_round256((size_t)ntiles * sizeof(int)) +
+                                       (snap_to_nearest ? mm_round256((size_t)npoints * 5 * sizeof(double)) : 0) +
+                                       mm_round256(sizeof(int) * (MM_KNN_MAX_K + 8)) + 4096);
+    if (rc != MM_OK) return rc;
+    int2 *qa = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    int2 *qb = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+    int *counters = (int *)mm_scratch_take(ctx, sizeof(int) * (MM_KNN_MAX_K + 8));
+    int *id_list = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
+    double *best_state = snap_to_nearest ? (double *)mm_scratch_take(ctx, (size_t)npoints * 4 * sizeof(double)) : nullptr;
+    i64 *best_elem_state = snap_to_nearest ? (i64 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(i64)) : nullptr;
+    MM_REQUIRE(qa && qb && counters && id_list && (!snap_to_nearest || (best_state && best_elem_state)),
+               "scratch carve failed");
+    MM_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int) * (MM_KNN_MAX_K + 8), ctx->stream));
+    if (k > 0 && nelem > 0) {
+        int2 *key_rank = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
+        int *ord = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
+        int *counts = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+        int *start = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
+        int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
+        MM_REQUIRE(key_rank && ord && counts && start && tile_sums, "scratch carve failed");
+        MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(nbins + 1) * sizeof(int), ctx->stream));
+        const unsigned gp = (unsigned)((npoints + 255) / 256);
+        hipLaunchKernelGGL((gll_key_kernel<IDX>), dim3(gp), dim3(256), 0, ctx->stream, (i64)kavail, npoints, nn, nelem,
+                           key_rank, counts);
+        rc = mm_exclusive_scan_int(ctx, counts, nbins, start, tile_sums);
+        if (rc != MM_OK) return rc;
+        hipLaunchKernelGGL(gll_order_kernel, dim3(gp), dim3(256), 0, ctx->stream, npoints, key_rank, start, ord);
+        visit = ord;
+    }
+    rc = MM_OK;
+#define MM_GLL_CASE(O, D)                                                                                          \
+    if (order == O && dim == D)                                                                                    \
+        rc = launch_locate<O, D, IDX>(ctx, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,       \
+                                      snap_to_nearest, em, nm, visit, qa, qb, counters, best_state, best_elem_state, \
+                                      lazy, id_list);
+    MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
+#undef MM_GLL_CASE
+    if (rc != MM_OK) return rc;
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
 
 extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k, int64_t npoints,
                                  const int64_t *nn_d, const double *gll_points_d, int64_t nelem,
@@ -745,65 +911,129 @@ extern "C" int64_t mm_locate_gll(mm_context *ctx, int order, int dim, int64_t k,
     MM_REQUIRE(order == 1 || order == 2 || order == 4, "order must be 1, 2 or 4");
     MM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
     MM_REQUIRE(k >= 0 && npoints >= 0 && nelem >= 0, "negative size");
+    MM_REQUIRE(k <= MM_KNN_MAX_K, "nelem_to_search must be <= MM_KNN_MAX_K");
     MM_REQUIRE(npoints == 0 || (elem_d && coeffs_d && points_d), "null array");
     MM_REQUIRE(npoints == 0 || k == 0 || (nn_d && gll_points_d), "null array");
-    MM_REQUIRE(npoints < (int64_t)0x7fffffff * 64, "too many targets for one launch");
+    MM_REQUIRE(npoints < (int64_t)0x7fffffff && nelem < (int64_t)0x7ffffff0, "too many targets / elements");
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(i64), ctx->stream));
-    MM_REQUIRE(npoints < (int64_t)0x7fffffff && nelem < (int64_t)0x7ffffff0, "too many targets / elements");
     if (npoints > 0) {
         mm_stage_begin(ctx, MM_STAGE_LOCATE);
-        unsigned long long *nm = (unsigned long long *)ctx->d_counters;
-        // scratch: visiting order, two pass queues, their counters, snap state
-        const int *visit = nullptr;
-        const i64 nbins = nelem + 1;
-        const i64 ntiles = (nbins + 1023) / 1024;
-        int rc = mm_scratch_begin(ctx, 3 * mm_round256((size_t)npoints * sizeof(int2)) +
-                                           mm_round256((size_t)npoints * sizeof(int)) +
-                                           2 * mm_round256((size_t)(nbins + 1) * sizeof(int)) +
-                                           mm_round256((size_t)ntiles * sizeof(int)) +
-                                           (snap_to_nearest ? mm_round256((size_t)npoints * 5 * sizeof(double)) : 0) +
-                                           mm_round256(sizeof(int) * (MM_KNN_MAX_K + 8)) + 4096);
-        if (rc != MM_OK) return rc;
-        int2 *qa = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
-        int2 *qb = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
-        int *counters = (int *)mm_scratch_take(ctx, sizeof(int) * (MM_KNN_MAX_K + 8));
-        double *best_state = snap_to_nearest ? (double *)mm_scratch_take(ctx, (size_t)npoints * 4 * sizeof(double)) : nullptr;
-        i64 *best_elem_state = snap_to_nearest ? (i64 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(i64)) : nullptr;
-        MM_REQUIRE(qa && qb && counters && (!snap_to_nearest || (best_state && best_elem_state)), "scratch carve failed");
-        MM_REQUIRE(k <= MM_KNN_MAX_K, "nelem_to_search must be <= MM_KNN_MAX_K");
-        MM_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int) * (MM_KNN_MAX_K + 8), ctx->stream));
-        if (k > 0 && nelem > 0) {
-            int2 *key_rank = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
-            int *ord = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
-            int *counts = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
-            int *start = (int *)mm_scratch_take(ctx, (size_t)(nbins + 1) * sizeof(int));
-            int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
-            MM_REQUIRE(key_rank && ord && counts && start && tile_sums, "scratch carve failed");
-            MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(nbins + 1) * sizeof(int), ctx->stream));
-            const unsigned gp = (unsigned)((npoints + 255) / 256);
-            hipLaunchKernelGGL(gll_key_kernel, dim3(gp), dim3(256), 0, ctx->stream, k, npoints, (const i64 *)nn_d, nelem,
-                               key_rank, counts);
-            rc = mm_exclusive_scan_int(ctx, counts, nbins, start, tile_sums);
-            if (rc != MM_OK) return rc;
-            hipLaunchKernelGGL(gll_order_kernel, dim3(gp), dim3(256), 0, ctx->stream, npoints, key_rank, start, ord);
-            visit = ord;
-        }
-        const i64 *nn = (const i64 *)nn_d;
-        i64 *el = (i64 *)elem_d;
-#define MM_GLL_CASE(O, D)                                                                                      \
-    if (order == O && dim == D)                                                                                \
-        launch_locate<O, D>(ctx, k, npoints, nn, gll_points_d, nelem, points_d, tolerance, snap_to_nearest, el, \
-                            coeffs_d, nm, visit, qa, qb, counters, best_state, best_elem_state);
-        MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
-#undef MM_GLL_CASE
+        GllEmit em = {(i64 *)elem_d, coeffs_d, nullptr, nullptr, 0};
+        int rc = locate_gll_run<i64>(ctx, order, dim, k, (int)k, npoints, (const i64 *)nn_d, gll_points_d, nelem,
+                                     points_d, tolerance, snap_to_nearest, em, nullptr);
         mm_stage_end(ctx, MM_STAGE_LOCATE);
-        MM_HIP_CHECK(hipGetLastError());
+        if (rc != MM_OK) return rc;
     }
     MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return ctx->h_counters[0];
+}
+
+// Mean of the control nodes of every element, summed in node order like NumPy's mean(axis=1)
+// (reference salvus_mesh_reader.py:99-100) -- the source points of the GLL path's centroid tree.
+template <int DIM>
+__global__ __launch_bounds__(256) void centroid_nodal_kernel(i64 nelem, int P, const double *__restrict__ gll_points,
+                                                             double *__restrict__ out)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nelem) return;
+    const double *row = gll_points + e * (i64)P * DIM;
+    double acc[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) acc[a] = row[a];
+    for (int p = 1; p < P; ++p)
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) acc[a] = acc[a] + row[p * DIM + a];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) out[e * DIM + a] = acc[a] / (double)P;
+}
+
+// The GLL form of the whole path on resident arrays (reference interpolator.py:931-977, and the core of
+// gll_2_gll :700-830): element centroids -> k nearest -> element + reference coordinates by the
+// acceptance loop of :1181-1233 -> sum of coefficient x element-nodal field value.  Without operator
+// outputs the weighted sum is formed where a target is accepted (no [N][P] coefficient array), and
+// the candidate lists are evaluated lazily (mm_set_lazy_lists) exactly as in mm_interpolate_hex8.
+extern "C" int64_t mm_interpolate_gll(mm_context *ctx, int order, int dim, const double *gll_points_d, int64_t nelem,
+                                      const double *points_d, int64_t npoints, const double *fields_d,
+                                      int64_t ncomp, int64_t k, double tolerance, int snap_to_nearest,
+                                      double *out_d, int64_t *elem_out_d, double *coeffs_out_d)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(order == 1 || order == 2 || order == 4, "order must be 1, 2 or 4");
+    MM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    MM_REQUIRE(k >= 1 && k <= MM_KNN_MAX_K, "nelem_to_search must be in 1..MM_KNN_MAX_K");
+    MM_REQUIRE(npoints >= 0 && nelem >= 1 && ncomp >= 0, "bad sizes");
+    MM_REQUIRE(npoints < (int64_t)0x7fffffff && nelem < (int64_t)0x7ffffff0, "too many targets / elements");
+    MM_REQUIRE(ncomp < (1 << 20), "ncomp too large");
+    MM_REQUIRE(gll_points_d && (npoints == 0 || points_d), "null array");
+    MM_REQUIRE(ncomp == 0 || npoints == 0 || (fields_d && out_d), "null array");
+    MM_REQUIRE((elem_out_d == nullptr) == (coeffs_out_d == nullptr), "element and coefficient outputs come together");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_stage_reset(ctx);
+    if (npoints == 0) return 0;
+    const int P = dim == 3 ? (order + 1) * (order + 1) * (order + 1) : (order + 1) * (order + 1);
+
+    double *cen = nullptr;
+    int rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * dim * sizeof(double), (void **)&cen);
+    if (rc != MM_OK) return rc;
+    mm_stage_begin(ctx, MM_STAGE_CENTROID);
+    {
+        const dim3 g((unsigned)((nelem + 255) / 256)), b(256);
+        if (dim == 3) hipLaunchKernelGGL((centroid_nodal_kernel<3>), g, b, 0, ctx->stream, nelem, P, gll_points_d, cen);
+        else hipLaunchKernelGGL((centroid_nodal_kernel<2>), g, b, 0, ctx->stream, nelem, P, gll_points_d, cen);
+    }
+    mm_stage_end(ctx, MM_STAGE_CENTROID);
+
+    mm_knn_index *ix = nullptr;
+    mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
+    rc = mm_knn_build_impl(ctx, cen, nelem, dim, &ix, /*use_context_buffers=*/true, nullptr, 0);
+    mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
+    if (rc != MM_OK) return rc;
+
+    const bool lazy_on = ctx->lazy_lists && k > kGllLazyK;
+    const int kavail = lazy_on ? kGllLazyK : (int)k;
+    int *nn = nullptr, *nn_full = nullptr;
+    rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * kavail * sizeof(int), (void **)&nn);
+    if (rc == MM_OK && lazy_on)
+        rc = mm_buffer_get(ctx, MM_BUF_NN_FULL, (size_t)npoints * k * sizeof(int), (void **)&nn_full);
+    if (rc == MM_OK) {
+        mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
+        rc = mm_knn_query_impl(ctx, ix, points_d, npoints, kavail, nn, nullptr, /*idx_is_int32=*/true);
+        mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
+    }
+    if (rc == MM_OK) {
+        hipError_t e = hipMemsetAsync(ctx->d_counters, 0, sizeof(i64), ctx->stream);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_HIP, "memset: %s", hipGetErrorString(e));
+            rc = MM_ERR_HIP;
+        }
+    }
+    if (rc == MM_OK) {
+        mm_stage_begin(ctx, MM_STAGE_LOCATE);
+        GllEmit em = {(i64 *)elem_out_d, coeffs_out_d, ncomp > 0 ? fields_d : nullptr, ncomp > 0 ? out_d : nullptr,
+                      (int)ncomp};
+        GllLazy lz = {ix, nn_full};
+        rc = locate_gll_run<int>(ctx, order, dim, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,
+                                 snap_to_nearest, em, lazy_on ? &lz : nullptr);
+        mm_stage_end(ctx, MM_STAGE_LOCATE);
+    }
+    int64_t result = rc;
+    if (rc == MM_OK) {
+        hipError_t e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_HIP, "pipeline: %s", hipGetErrorString(e));
+            result = MM_ERR_HIP;
+        } else {
+            result = ctx->h_counters[0];
+        }
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (ix) mm_knn_destroy(nullptr, ix);   // borrowed arrays stay in the context cache
+    return result;
 }
 
 extern "C" int mm_gather_elem(mm_context *ctx, const double *fields_d, int64_t nelem, int64_t ncomp,

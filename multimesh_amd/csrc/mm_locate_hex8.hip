@@ -235,7 +235,8 @@ __device__ __forceinline__ void emit_row(const Emit &em, i64 i, const i64 (&id)[
             double p[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) p[n] = f[sid[n]] * wt[n];
-            em.out[i * em.ncomp + c] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            // 0.0 + ...: NumPy starts the reduction from the identity (a row sum of -0.0 reads +0.0)
+            em.out[i * em.ncomp + c] = 0.0 + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
         }
     }
 }

@@ -281,6 +281,38 @@ class Context:
         return out
 
     # ---- fused ---------------------------------------------------------------------------
+    def interpolate_gll(self, shape_order, gll_points, points, element_nodal_fields, nelem_to_search=20,
+                        tolerance=1.05, snap_to_nearest=False, want_operator=False, out=None):
+        """The GLL form of the whole path (reference interpolator.py:931-977) on resident arrays:
+        gll_points f64[E, P, dim], points f64[N, dim], element_nodal_fields f64[C, E, P].
+        Returns (values f64[N, C], nmissing) or (values, elem int64[N], coeffs f64[N, P], nmissing)."""
+        gp = self.asdevice(gll_points, np.float64)
+        pts = self.asdevice(points, np.float64)
+        f = self.asdevice(element_nodal_fields, np.float64)
+        if len(f.shape) == 2:
+            f = DeviceArray(self, f.ptr, (1,) + f.shape, f.dtype, owner=False, keepalive=f)
+        nelem, P, dim = gp.shape
+        if P != (shape_order + 1) ** dim or len(pts.shape) != 2 or pts.shape[1] != dim:
+            raise ValueError("gll_points must be [nelem, (order+1)^dim, dim] and points [N, dim]")
+        if f.shape[1:] != (nelem, P):
+            raise ValueError("element_nodal_fields must be [C, nelem, P]")
+        n, ncomp = pts.shape[0], f.shape[0]
+        if out is None:
+            out = self.empty((n, ncomp), np.float64)
+        else:
+            out = self.asdevice(out, np.float64)
+            if out.shape != (n, ncomp):
+                raise ValueError("out must be [N, C]")
+        elem = self.empty((n,), np.int64) if want_operator else None
+        coeffs = self.empty((n, P), np.float64) if want_operator else None
+        miss = check(self.lib.mm_interpolate_gll(self.handle, shape_order, dim, gp.ptr, nelem, pts.ptr, n, f.ptr, ncomp,
+                                                 nelem_to_search, float(tolerance), 1 if snap_to_nearest else 0,
+                                                 out.ptr, elem.ptr if elem else None, coeffs.ptr if coeffs else None),
+                     "mm_interpolate_gll")
+        if want_operator:
+            return out, elem, coeffs, int(miss)
+        return out, int(miss)
+
     def interpolate_hex8(self, nodes, connectivity, points, fields, nelem_to_search=20, want_operator=False,
                          out=None):
         """The whole hot path of reference scripts/cli.py:62-100 on resident arrays.

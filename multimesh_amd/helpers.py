@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = (
     "mm_device_alloc", "mm_device_free", "mm_copy_h2d", "mm_copy_d2h", "mm_memset",
     "mm_centroid", "mm_knn_build", "mm_knn_query", "mm_knn_destroy",
     "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_locate_gll", "mm_gather_elem",
-    "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox",
+    "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
 )
 
 
@@ -120,6 +120,9 @@ def load_lib():
                                   C.c_int, vp, vp]
     lib.mm_gather_elem.restype = C.c_int
     lib.mm_gather_elem.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, C.c_int]
+    lib.mm_interpolate_gll.restype = C.c_int64
+    lib.mm_interpolate_gll.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64,
+                                       C.c_double, C.c_int, vp, vp, vp]
     lib.mm_locate_gll_bbox.restype = C.c_int64
     lib.mm_locate_gll_bbox.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp, C.c_int64, vp, vp, vp]
     lib.mm_unique_points.restype = C.c_int64

@@ -295,7 +295,7 @@ static double numpy_row_sum(const double *a, i64 n)
         for (int j = 0; j < 8; ++j) r[j] += a[i + j];
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < n; ++i) res += a[i];
-    return res;
+    return 0. + res; /* the reduction starts from the identity: a row sum of -0.0 reads +0.0 */
 }
 
 /* field: [ncomp][nsrc] (one contiguous array per component, as the reference
@@ -700,7 +700,7 @@ i64 mmo_locate_gll_v1(int order, int dim, i64 k, i64 npoints, const i64 *nn, con
 }
 
 /* Element-nodal gather: np.sum(coeffs * field[elem_indices], axis=1) (reference
- * interpolator.py:976); field [ncomp][nelem][P]; element -1 contributes zeros. */
+ * interpolator.py:976); field [ncomp][nelem][P]; element -1 contributes zeros (signed like NumPy's). */
 int mmo_gather_elem(const double *field, i64 nelem, i64 ncomp, const i64 *elem, const double *coeffs, i64 npoints,
                     i64 P, double *out, int out_point_major)
 {
@@ -709,7 +709,8 @@ int mmo_gather_elem(const double *field, i64 nelem, i64 ncomp, const i64 *elem, 
     for (i64 c = 0; c < ncomp; ++c) {
         const double *f = field + c * nelem * P;
         for (i64 i = 0; i < npoints; ++i) {
-            const i64 e = elem[i] >= 0 && elem[i] < nelem ? elem[i] : 0;
+            /* NumPy index semantics: -1 (not found, zero coefficients) reads the last element */
+            const i64 e = elem[i] >= 0 && elem[i] < nelem ? elem[i] : (elem[i] < 0 && elem[i] >= -nelem ? elem[i] + nelem : 0);
             for (i64 p = 0; p < P; ++p) prod[p] = coeffs[i * P + p] * f[e * P + p];
             const double v = numpy_row_sum(prod, P);
             if (out_point_major) out[i * ncomp + c] = v;

@@ -78,6 +78,14 @@ def test_locate_and_gather_reproduce_smooth_fields(order, dim):
     # literal NumPy statement of reference interpolator.py:976
     f = synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2])
     assert np.array_equal(O.gather_elem(f, elem, co)[:, 0], np.sum(co * f[elem], axis=1))
+    # points that were not found: element -1 and zero coefficients -> NumPy reads the LAST element,
+    # and the sign of the resulting zero follows the signs of its field values
+    elem_m, co_m = elem.copy(), co.copy()
+    elem_m[::3], co_m[::3] = -1, 0.0
+    for g in (f, -1.0 - np.abs(f)):
+        want = np.sum(co_m * g[elem_m], axis=1)
+        got = O.gather_elem(g, elem_m, co_m)[:, 0]
+        assert np.array_equal(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
 
 
 def test_control_flow_not_found_snap_and_tolerance():

@@ -56,6 +56,14 @@ def test_gather_order_is_numpys(golden, P):
     w = rng.normal(size=(200, P))
     assert np.array_equal(O.gather(f, ids, w), O.gather_numpy(f, ids, w))
     assert np.array_equal(O.gather(f, ids, w, point_major=False)[0], O.gather_numpy(f, ids, w)[:, 0])
+    # rows of a failed point (ids 0, weights 0.0 -- the caller's zero-initialised arrays, reference
+    # cli.py:77-78) over negative field values: every product is -0.0, NumPy's sum is +0.0 because
+    # the reduction starts from the identity
+    fneg = -1.0 - np.abs(f)
+    ids0, w0 = np.zeros((5, P), np.int64), np.zeros((5, P))
+    want = O.gather_numpy(fneg, ids0, w0)
+    got = O.gather(fneg, ids0, w0)
+    assert not np.signbit(want).any() and np.array_equal(np.signbit(got), np.signbit(want))
 
 
 def test_knn_brute_matches_ckdtree_fixture(golden):

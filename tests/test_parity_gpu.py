@@ -176,6 +176,17 @@ def test_gather_golden(ctx, golden, P):
     assert np.array_equal(ctx.gather(f[0], ids, w).numpy()[:, 0], d[f"values_P{P}"][:, 0])
 
 
+@pytest.mark.parametrize("P", [4, 8, 27])
+def test_gather_rows_of_failed_points_read_plus_zero(ctx, P):
+    # ids 0 / weights 0.0 (the caller's zero-initialised rows of a failed point, reference cli.py:77-78)
+    # over negative field values: every product is -0.0; NumPy's reduction starts from the identity
+    f = -1.0 - np.abs(np.random.default_rng(P).normal(size=(2, 50)))
+    ids, w = np.zeros((9, P), np.int64), np.zeros((9, P))
+    want = O.gather_numpy(f, ids, w)
+    got = ctx.gather(f, ids, w).numpy()
+    assert np.array_equal(got, want) and not np.signbit(got).any()
+
+
 def test_gather_ragged_sizes_vs_oracle(ctx):
     rng = np.random.default_rng(8)
     for n, P, C in [(1, 8, 1), (63, 8, 3), (65, 8, 2), (1000, 27, 3), (17, 125, 2), (5, 9, 1), (0, 8, 2)]:
@@ -334,6 +345,47 @@ def test_gll_locate_and_gather_equal_the_oracle(ctx, order, dim):
         assert np.array_equal(ctx.gather_elem(fields, elem, co, point_major=False).numpy(), vals.T)
         found = elem_o >= 0
         assert np.abs(vals[found, 0] - synth.field_linear(pts[found])).max() < 1e-11 or snap
+
+
+@pytest.mark.parametrize("order,dim", [(o, d) for o in (1, 2, 4) for d in (2, 3)])
+def test_gll_fused_pipeline_equals_staged_calls_and_oracle(ctx, order, dim):
+    # mm_interpolate_gll: centroids (NumPy mean order), kNN, acceptance loop, weighted sum formed at
+    # the point of acceptance, candidate lists evaluated lazily -- against cKDTree + the oracle's
+    # locate + the oracle's NumPy-order gather, values-only and with the operator, lazy and eager.
+    gp = synth.gll_mesh(7 if dim == 3 else 12, order, seed=9, jitter=0.25, dim=dim)
+    # shear the mesh so that a good share of the targets is NOT in one of its 8 nearest elements
+    gp = gp.copy()
+    gp[..., 0] += 1.7 * gp[..., 1]
+    rng = np.random.default_rng(10 * order + dim)
+    lo, hi = gp.reshape(-1, dim).min(axis=0), gp.reshape(-1, dim).max(axis=0)
+    pts = rng.uniform(lo - 0.02, hi + 0.02, size=(6000, dim))         # the sheared box: many outside
+    cen = gp.mean(axis=1)
+    k = min(20, gp.shape[0])
+    fields = np.stack([synth.field_linear(gp), synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2]),
+                       -1.0 - synth.field_linear(gp) ** 2])
+    nn = O.knn_ckdtree(cen, pts, k)[0]
+    for tol, snap in ((1.05, False), (1.05, True)):
+        elem_o, co_o, miss_o = O.locate_gll(order, nn, gp, pts, tolerance=tol, snap_to_nearest=snap)
+        vals_o = O.gather_elem(fields, elem_o, co_o)
+        beyond8 = int(((elem_o[:, None] != nn[:, :8]).all(axis=1) & (elem_o >= 0)).sum())
+        assert snap or (miss_o > 0 and (k <= 8 or beyond8 > 0))
+        for lazy in (True, False):
+            ctx.set_lazy_lists(lazy)
+            try:
+                vals, miss = ctx.interpolate_gll(order, gp, pts, fields, nelem_to_search=k, tolerance=tol,
+                                                 snap_to_nearest=snap)
+                v2, elem, co, miss2 = ctx.interpolate_gll(order, gp, pts, fields, nelem_to_search=k, tolerance=tol,
+                                                          snap_to_nearest=snap, want_operator=True)
+            finally:
+                ctx.set_lazy_lists(True)
+            assert miss == miss_o == miss2
+            assert np.array_equal(vals.numpy(), vals_o) and np.array_equal(v2.numpy(), vals_o)
+            # the sign of the zeros of points that were not found follows NumPy's field[-1] * 0.0
+            assert np.array_equal(np.signbit(vals.numpy()), np.signbit(vals_o))
+            assert np.array_equal(elem.numpy(), elem_o) and np.array_equal(co.numpy(), co_o)
+        # one component, and none
+        v1, _ = ctx.interpolate_gll(order, gp, pts, fields[1], nelem_to_search=k, tolerance=tol, snap_to_nearest=snap)
+        assert np.array_equal(v1.numpy()[:, 0], vals_o[:, 1])
 
 
 def test_gll_api_and_cfg5_shaped_run(ctx):
