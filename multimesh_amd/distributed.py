@@ -101,3 +101,37 @@ class HipShardInterpolator:
         _, nfailed = self.ctx.interpolate_hex8(self.nodes, self.conn, pts, self.fields,
                                                nelem_to_search=self.k, out=out)
         return out, nfailed
+
+
+class HipShardGllInterpolator:
+    """The GLL counterpart (reference interpolator.py:931-977, whose per-process chunks of targets
+    are this sharding, :1239-1251): element-nodal source mesh and fields replicated on this rank's
+    GPU, the fused GLL path (``mm_interpolate_gll``) per shard of target points."""
+
+    def __init__(self, gll_points, shape_order, element_nodal_fields, nelem_to_search=20, tolerance=1.05,
+                 device_index=None):
+        import torch
+
+        from .device import Context
+
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        self.ctx = Context(device_index, stream=torch.cuda.current_stream(self.device).cuda_stream)
+        self.order, self.k, self.tolerance = int(shape_order), nelem_to_search, float(tolerance)
+        as_dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)  # noqa: E731
+        self.gll_points = as_dev(gll_points)                       # [E, P, dim]
+        f = np.asarray(element_nodal_fields, dtype=np.float64)
+        self.fields = as_dev(f[None] if f.ndim == 2 else f)        # [C, E, P]
+
+    def __call__(self, points_shard):
+        import torch
+
+        pts = torch.as_tensor(np.ascontiguousarray(points_shard, dtype=np.float64)).to(self.device) \
+            if not hasattr(points_shard, "data_ptr") else points_shard.contiguous()
+        out = torch.empty((pts.shape[0], self.fields.shape[0]), dtype=torch.float64, device=self.device)
+        if pts.shape[0] == 0:
+            return out, 0
+        _, missing = self.ctx.interpolate_gll(self.order, self.gll_points, pts, self.fields,
+                                              nelem_to_search=self.k, tolerance=self.tolerance, out=out)
+        return out, missing

@@ -96,6 +96,19 @@ def _rank(rank, world, port, tmpdir):
         vals, nfailed = interpolate_sharded(pb, local)
         np.save(os.path.join(tmpdir, f"v{rank}.npy"), vals.numpy())
         assert nfailed == 0
+        # the GLL path shards the same way
+        from multimesh_amd.distributed import HipShardGllInterpolator
+
+        gp = synth.gll_mesh(6, 2, seed=3)
+        gll = HipShardGllInterpolator(gp, 2, synth.field_linear(gp), nelem_to_search=20, device_index=0)
+
+        def local_gll(shard):
+            out, nm = gll(shard)
+            return out.cpu(), nm
+
+        gvals, gmiss = interpolate_sharded(pb[:5001], local_gll)
+        np.save(os.path.join(tmpdir, f"g{rank}.npy"), gvals.numpy())
+        assert gmiss == 0
     finally:
         dist.destroy_process_group()
 
@@ -114,6 +127,13 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
     assert nf == 0
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"v{r}.npy"), single)        # partition independent
+    gp = synth.gll_mesh(6, 2, seed=3)
+    with Context(0) as ctx:
+        gsingle, gm = ctx.interpolate_gll(2, gp, pb[:5001], synth.field_linear(gp))
+        gsingle = gsingle.numpy()
+    assert gm == 0 and np.abs(gsingle[:, 0] - synth.field_linear(pb[:5001])).max() < 1e-11
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"g{r}.npy"), gsingle)
 
 
 # ------------------------------------------------------------------------------- A11
