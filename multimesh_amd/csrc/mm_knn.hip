@@ -37,6 +37,8 @@ constexpr double kRefineShare = 0.25;
 constexpr int kMaxRefine = 1;   // a second level costs more on the sparse side than it saves
 constexpr i64 kRefineMinSources = 4096;
 constexpr double kRefineMaxCellsPerSource = 8.0;
+constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
+constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
 
 struct GridParams {
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                                                              IDX *__restrict__ idx_out,
                                                              double *__restrict__ dist_out,
                                                              int *__restrict__ fb_list, int *__restrict__ fb_count,
-                                                             int dbg_stop)
+                                                             int dbg_stop, int nsplit)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
 #ifndef MM_STRIP_NB_SMALL   // tuning builds only
@@ -1003,17 +1005,29 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     const int cols_per_xcd = (ncols + 7) / 8;
     const int nstrips = (g.nz + kStripZ - 1) / kStripZ;
     const int xcd = blockIdx.x & 7;
-    const int m = blockIdx.x >> 3;
+    // nsplit > 1 (many more targets than sources, e.g. the unique GLL points of a fine mesh over a
+    // coarse one): nsplit waves per strip -- consecutive workgroups of one XCD -- share its targets
+    int m = blockIdx.x >> 3, part = 0;
+    if (nsplit > 1) {
+        part = m % nsplit;
+        m = m / nsplit;
+    }
     const int colm = m / nstrips;
     const int col = xcd * cols_per_xcd + colm;
     if (colm >= cols_per_xcd || col >= ncols) return;
     const int strip = m - colm * nstrips;
     const int cx = col / g.ny, cy = col - cx * g.ny;
     const int cz0 = strip * kStripZ, cz1 = min(cz0 + kStripZ, g.nz);
-    const int t0 = tstart[col * g.nz + cz0];
+    int t0 = tstart[col * g.nz + cz0];
     const int t1 = tstart[col * g.nz + cz1];
-    const int tn = t1 - t0;
-    if (tn == 0) return;
+    int tn = t1 - t0;
+    if (nsplit > 1) {
+        // whole rounds of kStripGroups targets per part
+        const int chunk = ((tn + nsplit - 1) / nsplit + kStripGroups - 1) / kStripGroups * kStripGroups;
+        t0 += part * chunk;
+        tn = min(chunk, t1 - t0);
+    }
+    if (tn <= 0) return;
     const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
     const int nlayers = zb - za + 1;
     const int ntc = nlayers * 9;
@@ -1459,10 +1473,19 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     if (use_strip) {
         const i64 nstrips = (ix->dims[2] + kStripZ - 1) / kStripZ;
-        const i64 strip_grid = 8 * ((cols + 7) / 8) * nstrips;
+        i64 strip_grid = 8 * ((cols + 7) / 8) * nstrips;
+        // a strip's rounds are sequential in its wave: with many more targets than sources (a few
+        // thousand strips of a thousand targets each) the strips are shared out, ~kSplitTargets each
+        const i64 per_strip = npts / (cols * nstrips > 0 ? cols * nstrips : 1);
+        i64 nsplit = (per_strip + kSplitTargets / 2) / kSplitTargets;
+        static const int force_split = getenv("MM_KNN_SPLIT") ? atoi(getenv("MM_KNN_SPLIT")) : 0;
+        if (force_split > 0) nsplit = force_split;
+        nsplit = nsplit < 1 ? 1 : (nsplit > kMaxSplit ? kMaxSplit : nsplit);
+        while (nsplit > 1 && strip_grid * nsplit > (i64)0x7fffffff) --nsplit;
+        strip_grid *= nsplit;
         hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX>), dim3((unsigned)strip_grid), dim3(kWave), 0, ctx->stream, g,
                            ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist,
-                           fb_list, fb_count, dbg_stop);
+                           fb_list, fb_count, dbg_stop, (int)nsplit);
     } else {
         hipLaunchKernelGGL((knn_cell_kernel<K, CAP, IDX>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
                            ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);

@@ -415,6 +415,16 @@ def test_knn_many_targets_per_cell_multi_round(ctx):
     assert np.array_equal(ctx.knn_build(src).query(q, 20).numpy(), O.knn_ckdtree(src, q, 20, workers=-1)[0])
 
 
+@pytest.mark.parametrize("k", [8, 20])
+def test_knn_strips_shared_between_waves(ctx, k):
+    # ~1,400 targets per strip of two cells (the unique GLL points of a fine mesh over the centroids of a
+    # coarse one look like this): each strip's targets are shared out between several waves
+    rng = np.random.default_rng(13)
+    src = rng.uniform(size=(6_000, 3))
+    q = rng.uniform(size=(520_003, 3))
+    assert np.array_equal(ctx.knn_build(src).query(q, k).numpy(), O.knn_ckdtree(src, q, k, workers=-1)[0])
+
+
 def test_knn_few_targets_wide_groups(ctx):
     # far fewer targets than cells: one target per wave, all 64 lanes on it
     rng = np.random.default_rng(12)
