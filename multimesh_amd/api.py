@@ -260,10 +260,66 @@ def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to
     return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(list(params)), tgt.shape[0], tgt.shape[1])
 
 
+def find_gll_centroids(gll_coordinates, dimensions=3):
+    """The reference's ``_find_gll_centroids`` (interpolator.py:1389-1406): per-dimension
+    ``np.mean(gll_coordinates[:, :, d], axis=1)`` -- NumPy's pairwise row sum over the strided view,
+    not the node-order sum of ``mean(axis=1)`` on the 3-D array that the mesh reader uses; kept on the
+    host in NumPy so that the tree is built over bit-identical centroids (an O(E P) pass)."""
+    gll_coordinates = np.asarray(gll_coordinates, dtype=np.float64)
+    if dimensions != gll_coordinates.shape[2]:
+        raise ValueError("Dimensions of GLL model not the same as input")
+    centroids = np.zeros(shape=[gll_coordinates.shape[0], dimensions])
+    for d in range(dimensions):
+        centroids[:, d] = np.mean(gll_coordinates[:, :, d], axis=1, dtype=np.float64)
+    return centroids
+
+
+def interpolate_gll_to_nodes(gll_points, gll_data, points, shape_order=4, nelem_to_search=20, context=None):
+    """The array core of ``gll_2_exodus`` (reference interpolator.py:227-285): centroid tree over the
+    GLL elements, ``nelem_to_search`` nearest per mesh node, the bounding-box acceptance loop
+    ``_check_if_inside_element`` (:1409-1473) and ``np.sum(gll_data[element, :, :] * coeffs, axis=1)``.
+    ``gll_points`` f64[E, P, dim], ``gll_data`` f64[E, C, P] (the layout of the HDF5 ``MODEL/data``),
+    ``points`` f64[N, dim] -> values f64[N, C]."""
+    ctx = context or default_context()
+    gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)
+    dim = gll_points.shape[2]
+    tree = ctx.knn_build(find_gll_centroids(gll_points, dim))
+    pts = ctx.asdevice(np.ascontiguousarray(points, dtype=np.float64), np.float64)
+    nn = tree.query(pts, nelem_to_search)
+    elem, coeffs, _ = ctx.locate_gll_bbox(shape_order, nn, gll_points, pts)
+    fields = np.ascontiguousarray(np.asarray(gll_data, dtype=np.float64).transpose(1, 0, 2))   # [C, E, P]
+    return ctx.gather_elem(fields, elem, coeffs).numpy()
+
+
+def query_gll_model(gll_points, gll_data, coordinates, nelem_to_search=20, ignore_hard_elements=False, context=None):
+    """The array core of ``query_model`` (reference interpolator.py:60-139) after its file read and
+    ``latlondepth_to_xyz``: a tree over ALL GLL points (not the centroids), the ``nelem_to_search``
+    nearest points per coordinate mapped to their elements by ``floor(index / P)`` (an element can
+    appear several times in a list), ``find_gll_coeffs`` = the bounding-box acceptance loop
+    (:1409-1473), then ``np.sum(original_data[elements] * coeffs, axis=2)``.
+    ``gll_points`` f64[E, P, dim], ``gll_data`` f64[E, C, P], ``coordinates`` f64[N, dim] (Cartesian)
+    -> values f64[N, C].  Like the reference it raises ``ValueError`` when no candidate element
+    admits an inverse transform, unless ``ignore_hard_elements``.  Equidistant points (the copies of
+    a node shared by several elements) are ordered by index here; cKDTree's order among them is
+    unspecified."""
+    ctx = context or default_context()
+    gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)
+    nelem, P, dim = gll_points.shape
+    gll_order = int(round(P ** (1.0 / dim))) - 1
+    tree = ctx.knn_build(gll_points.reshape(nelem * P, dim))
+    pts = ctx.asdevice(np.ascontiguousarray(coordinates, dtype=np.float64), np.float64)
+    nearest = np.floor(tree.query(pts, nelem_to_search).numpy() / P).astype(np.int64)
+    elem, coeffs, hard = ctx.locate_gll_bbox(gll_order, nearest, gll_points, pts)
+    if hard and not ignore_hard_elements:
+        raise ValueError("Can't find an appropriate element.")
+    fields = np.ascontiguousarray(np.asarray(gll_data, dtype=np.float64).transpose(1, 0, 2))   # [C, E, P]
+    return ctx.gather_elem(fields, elem, coeffs).numpy()
+
+
 def _gll(name, row):
     def f(*args, **kwargs):
-        raise NotImplementedError(f"{name}: the GLL (salvus.fem backed) path is SURVEY.md §8 row {row}; "
-                                  "only the hex8 path of the reference's own C library is implemented so far")
+        raise NotImplementedError(f"{name}: file-level driver (HDF5 / exodus I/O through h5py, pyexodus and salvus, "
+                                  f"none of which is available here) -- SURVEY.md §8 row {row}")
     f.__name__ = name
     return f
 
@@ -273,5 +329,5 @@ gll_2_gll = _gll("gll_2_gll", "A10 -- array core: interpolate_gll_to_gll; file I
 gll_2_gll_layered = _gll("gll_2_gll_layered", "A10 / §8f-4")
 gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "A10 / §8f-4")
 gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "A10 / §8f-4")
-gll_2_exodus = _gll("gll_2_exodus", "§8f-2 (file I/O) -- array core: interpolate_gll_to_points")
-query_model = _gll("query_model", "A10")
+gll_2_exodus = _gll("gll_2_exodus", "§8f-2 (file I/O) -- array core: interpolate_gll_to_nodes")
+query_model = _gll("query_model", "§8f-2 (file I/O) -- array core: query_gll_model")

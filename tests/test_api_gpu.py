@@ -202,3 +202,47 @@ def test_hex8_to_gll_on_arrays_equals_the_pointwise_path():
     flat = api.interpolate_to_points(mesh, tgt.reshape(-1, 3), ["f1", "f2"], nelem_to_search=20)
     assert np.array_equal(out.reshape(2, -1).T, flat)               # same bits as one call per point
     assert np.abs(out[0] - synth.field_linear(tgt)).max() < 1e-7    # trilinear field reproduced
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,dim", [(4, 3), (2, 2)])
+def test_gll_to_mesh_nodes_array_core_of_gll_2_exodus(order, dim):
+    # reference interpolator.py:227-285 spelled out with the oracle: per-dimension np.mean centroids,
+    # k-d tree, bounding-box acceptance loop, np.sum(gll_data[element, :, :] * coeffs, axis=1)
+    from multimesh_amd import api
+
+    gp = synth.gll_mesh(6 if dim == 3 else 9, order, seed=5, dim=dim)
+    rng = np.random.default_rng(3)
+    data = np.stack([synth.field_linear(gp), synth.field_smooth(gp.reshape(-1, dim)).reshape(gp.shape[:2]),
+                     rng.normal(size=gp.shape[:2])], axis=1)                      # [E, C, P] like MODEL/data
+    pts = rng.uniform(0.0, 1.0, size=(4000, dim))
+    vals = api.interpolate_gll_to_nodes(gp, data, pts, shape_order=order, nelem_to_search=20)
+    cen = np.stack([np.mean(gp[:, :, d], axis=1, dtype=np.float64) for d in range(dim)], axis=1)
+    assert np.array_equal(api.find_gll_centroids(gp, dim), cen)
+    nn, _ = O.knn_ckdtree(cen, pts, min(20, len(gp)))
+    elem, coeffs, _ = O.locate_gll_v1(order, nn, gp, pts)
+    want = np.stack([np.sum(data[elem[s], :, :] * coeffs[s], axis=1) for s in range(len(pts))])
+    assert np.array_equal(vals, want)
+    assert np.abs(vals[:, 0] - synth.field_linear(pts)).max() < 1e-11
+
+
+@pytest.mark.gpu
+def test_query_gll_model_array_core():
+    # reference interpolator.py:60-139: tree over all GLL points, floor(index / P) -> element lists with
+    # repeats, bounding-box loop, np.sum(original_data[elements] * coeffs, axis=2).  The copies of a
+    # shared node are equidistant: the brute-force oracle orders them by index like the device.
+    from multimesh_amd import api
+
+    gp = synth.gll_mesh(5, 2, seed=8, dim=3)                                     # 64 elements x 27 nodes
+    rng = np.random.default_rng(4)
+    data = np.stack([synth.field_linear(gp), rng.normal(size=gp.shape[:2])], axis=1)   # [E, C, P]
+    pts = rng.uniform(0.02, 0.98, size=(1500, 3))
+    vals = api.query_gll_model(gp, data, pts, nelem_to_search=20)
+    P = gp.shape[1]
+    nearest = np.floor(O.knn_brute(gp.reshape(-1, 3), pts, 20) / P).astype(np.int64)
+    assert (np.sort(nearest, axis=1)[:, 1:] == np.sort(nearest, axis=1)[:, :-1]).any()   # repeats do occur
+    elem, coeffs, hard = O.locate_gll_v1(2, nearest, gp, pts)
+    assert hard == 0
+    want = np.sum(data[elem] * coeffs[:, None, :], axis=2)
+    assert np.array_equal(vals, want)
+    assert np.abs(vals[:, 0] - synth.field_linear(pts)).max() < 1e-11
