@@ -318,7 +318,7 @@ def main():
                                    "note": "one step fed from pageable host arrays (H2D + kernels + D2H); not `value`"}
             del vals_h
         if world == 1 and not args.no_cpu_baseline:
-            stride = args.cpu_sample_stride or max(1, n_local // 1_000_000)
+            stride = args.cpu_sample_stride or max(1, n_local // 2_500_000)   # ~12 s of single-threaded CPU work
             base, (stride, enc_c, w_c, vals_c) = cpu_baseline(pa, ca, pb, fields, k, stride)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu_baseline"] = value / base["value"]
