@@ -536,3 +536,39 @@ def test_knn_graded_cloud_relaid_grid(ctx, power, monkeypatch):
         idx, dist = tree.query(q, 20, want_dist=True)
         assert np.array_equal(idx.numpy().reshape(len(q), 20), ref.reshape(len(q), 20))
         np.testing.assert_allclose(dist.numpy().reshape(len(q), 20), dref.reshape(len(q), 20), rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_bad_arguments_are_refused_with_a_code_and_a_message(ctx):
+    # the reference has no error channel at all; ours: negative MM_ERR_* and a
+    # thread-local message, nothing launched, and the context stays usable
+    lib, h = ctx.lib, ctx.handle
+    pa, ca = synth.hex_mesh(5, seed=1)
+    d_nodes, d_conn, d_pts = ctx.to_device(pa), ctx.to_device(ca), ctx.to_device(pa[:10])
+    d_f = ctx.to_device(pa[:, 0].copy())
+    out = ctx.empty((10, 1), np.float64)
+    MM_ERR_ARG = -1
+    cases = [
+        lambda: lib.mm_interpolate_hex8(h, d_nodes.ptr, len(pa), d_conn.ptr, len(ca), d_pts.ptr, 10, d_f.ptr, 1, 0,
+                                        out.ptr, None, None),                      # k = 0
+        lambda: lib.mm_interpolate_hex8(h, d_nodes.ptr, len(pa), d_conn.ptr, len(ca), d_pts.ptr, 10, d_f.ptr, 1, 65,
+                                        out.ptr, None, None),                      # k > MM_KNN_MAX_K
+        lambda: lib.mm_interpolate_hex8(h, None, len(pa), d_conn.ptr, len(ca), d_pts.ptr, 10, d_f.ptr, 1, 20,
+                                        out.ptr, None, None),                      # null nodes
+        lambda: lib.mm_interpolate_hex8(h, d_nodes.ptr, len(pa), d_conn.ptr, len(ca), d_pts.ptr, -1, d_f.ptr, 1, 20,
+                                        out.ptr, None, None),                      # negative size
+        lambda: lib.mm_centroid(h, 4, len(ca), 8, d_conn.ptr, d_nodes.ptr, out.ptr),                 # ndim = 4
+        lambda: lib.mm_knn_query(h, None, d_pts.ptr, 10, 5, out.ptr, None),                           # null index
+        lambda: lib.mm_gather(h, d_f.ptr, len(pa), 1, None, None, 10, 8, out.ptr, 1),                 # null operator
+        lambda: lib.mm_gather(h, d_f.ptr, len(pa), 1, d_conn.ptr, d_nodes.ptr, 10, 129, out.ptr, 1),  # P too large
+        lambda: lib.mm_locate_gll(h, 3, 3, 5, 10, d_conn.ptr, d_nodes.ptr, 1, d_pts.ptr, 1.05, 0, out.ptr, out.ptr),
+        lambda: lib.mm_interpolate_gll(h, 4, 3, d_nodes.ptr, 1, d_pts.ptr, 10, d_f.ptr, 1, 20, 1.05, 0, out.ptr,
+                                       out.ptr, None),                             # operator outputs: both or neither
+        lambda: lib.mm_unique_points(h, d_pts.ptr, 10, 4, out.ptr, out.ptr),                          # dim = 4
+    ]
+    for call in cases:
+        assert call() == MM_ERR_ARG
+        assert len(lib.mm_last_error()) > 0
+    # still alive
+    vals, nf = ctx.interpolate_hex8(pa, ca, pa[:10], pa[:, 0].copy(), nelem_to_search=20)
+    assert nf == 0 and np.abs(vals.numpy()[:, 0] - pa[:10, 0]).max() < 1e-7    # Newton tolerance 1e-8 x element size
