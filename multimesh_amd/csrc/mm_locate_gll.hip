@@ -821,10 +821,28 @@ __global__ __launch_bounds__(256) void gll_key_kernel(i64 k, i64 npoints, const 
                                                       int2 *__restrict__ key_rank, int *__restrict__ counts)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npoints) return;
-    const i64 e = (i64)nn[t * k];
-    const int key = (unsigned long long)e < (unsigned long long)nelem ? (int)e : (int)nelem;  // invalid -> last bin
-    key_rank[t] = make_int2(key, atomicAdd(&counts[key], 1));
+    const bool live = t < npoints;
+    int key = -1;
+    if (live) {
+        const i64 e = (i64)nn[t * k];
+        key = (unsigned long long)e < (unsigned long long)nelem ? (int)e : (int)nelem;  // invalid -> last bin
+    }
+    // targets in mesh order arrive in runs with the same first candidate, and same-address atomics
+    // serialise in L2: one atomic per run inside the wave (as in the kNN stage's cell_count_kernel)
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));
+    const int head_lane = 63 - __clzll((long long)upto);
+    const unsigned long long after = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+    int base = 0;
+    if (head && live) {
+        const int next_head = after ? __ffsll((long long)after) - 1 : 64;
+        base = atomicAdd(&counts[key], next_head - lane);
+    }
+    base = __shfl(base, head_lane);
+    if (live) key_rank[t] = make_int2(key, base + (lane - head_lane));
 }
 
 __global__ __launch_bounds__(256) void gll_order_kernel(i64 npoints, const int2 *__restrict__ key_rank,
