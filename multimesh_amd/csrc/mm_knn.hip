@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     __shared__ int s_layer[kStripLayers + 1];
 
     const int lane = threadIdx.x;
+    if (dbg_stop == 100) return;   // diagnostic: what dispatching the grid alone costs
     // XCD-aware strip -> workgroup map (see knn_cell_kernel): XCD x owns a slab of columns
     const int ncols = g.nx * g.ny;
     const int cols_per_xcd = (ncols + 7) / 8;
@@ -1018,6 +1019,22 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     const int strip = m - colm * nstrips;
     const int cx = col / g.ny, cy = col - cx * g.ny;
     const int cz0 = strip * kStripZ, cz1 = min(cz0 + kStripZ, g.nz);
+    // the tile's cell extents are requested before the strip's target range is looked at: both
+    // round trips are in flight together (a strip without targets throws them away)
+    const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
+    const int nlayers = zb - za + 1;
+    const int ntc = nlayers * 9;
+    const int layer = lane / 9, c = lane - layer * 9;
+    int s0 = 0, cnt = 0;
+    {
+        const int ix = cx + c / 3 - 1, iy = cy + (c - (c / 3) * 3) - 1;
+        const bool inside = lane < ntc && (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny;
+        if (inside) {
+            const int cellid = (ix * g.ny + iy) * g.nz + za + layer;
+            s0 = cell_start[cellid];
+            cnt = cell_start[cellid + 1] - s0;
+        }
+    }
     int t0 = tstart[col * g.nz + cz0];
     const int t1 = tstart[col * g.nz + cz1];
     int tn = t1 - t0;
@@ -1028,9 +1045,6 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         tn = min(chunk, t1 - t0);
     }
     if (tn <= 0) return;
-    const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
-    const int nlayers = zb - za + 1;
-    const int ntc = nlayers * 9;
     const double ox = g.lox + (double)cx * g.hx;
     const double oy = g.loy + (double)cy * g.hy;
     const double oz = g.loz + (double)cz0 * g.hz;
@@ -1051,15 +1065,6 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     // ---- stage the tile: lane l copies cell l of the (layer, column) list
     int total;
     {
-        const int layer = lane / 9, c = lane - layer * 9;
-        const int ix = cx + c / 3 - 1, iy = cy + (c - (c / 3) * 3) - 1;
-        const bool inside = lane < ntc && (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny;
-        int s0 = 0, cnt = 0;
-        if (inside) {
-            const int cellid = (ix * g.ny + iy) * g.nz + za + layer;
-            s0 = cell_start[cellid];
-            cnt = cell_start[cellid + 1] - s0;
-        }
         int incl = cnt;
         for (int d = 1; d < kWave; d <<= 1) {
             const int t = __shfl_up(incl, d);
