@@ -53,7 +53,7 @@ def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
 
 #: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
-KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_strip_kernel<8, 16, int>",
+KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_strip_kernel<8, 16, int, 0>",
                    "locate_pass0": "locate_pass_kernel<true, int> (first pass)", "gather": "gather8_kernel<true>"}
 
 

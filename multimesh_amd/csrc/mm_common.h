@@ -124,4 +124,5 @@ struct mm_knn_index {
     int *cell_start = nullptr;     // [ncells + 1] exclusive prefix of per-cell counts
     double *sorted_xyz = nullptr;  // [nsrc][4] records {x, y, z, original index bits} in cell order
     bool borrowed = false;         // arrays belong to the context's buffer cache (fused pipeline)
+    mm_knn_index *fine = nullptr;  // next density level: a grid over the same sources with smaller cells (owned)
 };

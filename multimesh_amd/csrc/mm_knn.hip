@@ -30,13 +30,21 @@ namespace {
 constexpr int kBlock = 256;
 constexpr double kDefaultPerCell = 8.0;  // average sources per cell: the k = 20 ball (radius ~0.84 cell) fits the 3x3x3 block
 constexpr int kMaxCellsPerAxis = 1024;
-// adaptive grid (mm_knn_build_impl): a cell is overfull above kOverfullCount sources; when more than
-// kRefineShare of the sources sit in overfull cells the grid is laid out again with 8x the cells
-constexpr int kOverfullCount = 24;
-constexpr double kRefineShare = 0.25;
-constexpr int kMaxRefine = 1;   // a second level costs more on the sparse side than it saves
-constexpr i64 kRefineMinSources = 4096;
-constexpr double kRefineMaxCellsPerSource = 8.0;
+// Density levels (mm_knn_build_impl).  The tiled kernels take a target whose neighbourhood holds
+// between ~0.46x and ~1.2x the density the grid was laid out for (enough sources in the 3x3x3 block
+// that it contains the k-th neighbour, few enough that the strip's cells fit the tile).  A cloud whose
+// density varies more than that gets further grids over the same sources, each laid out for
+// kLevelRatio times the density of the one before; a target whose strip overflows the tile at one
+// level is passed down to the next.  Level l (design density kLevelRatio^l times level 0's) is added
+// when more than kLevelShare of the sources sit in level-0 cells holding between kLevelCount[l-1] and
+// kLevelCount[l] points (the first threshold is well above what the Poisson noise of a uniform cloud
+// reaches); bands without sources get no grid.
+constexpr double kLevelRatio = 2.0;
+constexpr int kMaxLevels = 9;
+constexpr int kLevelCount[kMaxLevels - 1] = {15, 19, 38, 77, 154, 307, 614, 1229};   // ~9.6 x ratio^(l-1); 15: noise
+constexpr double kLevelShare = 0.02;   // of the sources, in the band of level-0 cell counts a level serves
+constexpr i64 kLevelMinSources = 4096;
+constexpr i64 kLevelMaxCells = (i64)1 << 27;
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
@@ -115,28 +123,35 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
     return (int)t;
 }
 
-// Sum of the counts of the cells holding more than kOverfullCount sources (adaptive grid statistic).
-__global__ __launch_bounds__(kBlock) void overfull_share_kernel(const int *__restrict__ counts, i64 ncells,
-                                                                unsigned long long *__restrict__ total)
+// total[b] += the counts of the cells holding more than kLevelCount[b] sources (density levels).
+__global__ __launch_bounds__(kBlock) void level_share_kernel(const int *__restrict__ counts, i64 ncells,
+                                                             unsigned long long *__restrict__ total)
 {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    int v = c < ncells ? counts[c] : 0;
-    if (v <= kOverfullCount) v = 0;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0 && v > 0) atomicAdd(total, (unsigned long long)v);
+    const int v = c < ncells ? counts[c] : 0;
+#pragma unroll
+    for (int b = 0; b < kMaxLevels - 1; ++b) {
+        int w = v > kLevelCount[b] ? v : 0;
+        if (!__any(w > 0)) break;   // thresholds ascend
+        for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+        if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(total + b, (unsigned long long)w);
+    }
 }
 
+// With `list` the items are the points list[0 .. *list_count) (a density level's share of the targets).
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
                                                             GridParams g, int2 *__restrict__ cell_of,
-                                                            int *__restrict__ counts)
+                                                            int *__restrict__ counts, const int *__restrict__ list,
+                                                            const int *__restrict__ list_count)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = e < nsrc;
+    const bool live = e < (list ? (i64)*list_count : nsrc);
     int c = -1;
     if (live) {
-        const double x = src[e * ndim];
-        const double y = ndim > 1 ? src[e * ndim + 1] : 0.0;
-        const double z = ndim > 2 ? src[e * ndim + 2] : 0.0;
+        const i64 p = list ? (i64)list[e] : e;
+        const double x = src[p * ndim];
+        const double y = ndim > 1 ? src[p * ndim + 1] : 0.0;
+        const double z = ndim > 2 ? src[p * ndim + 2] : 0.0;
         const int cx = cell_coord(x, g.lox, g.ihx, g.nx);
         const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
         const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
@@ -938,7 +953,10 @@ constexpr int kStripGroups = MM_STRIP_GROUPS;            // targets per round at
 constexpr int kStripSlots = kTileCap / (kWave / kStripGroups);   // window entries per lane at the narrowest split
 static_assert(kStripLayers * 9 <= kWave, "one lane stages one tile cell");
 
-template <int K, int CAP, typename IDX>
+// MODE 0: one grid (the common case: no code for anything else).  1: level 0 of a graded cloud (targets
+// whose strip is too full are passed down).  2: a denser level -- the workgroups walk the list of the
+// strips that hold targets instead of being one workgroup per strip of the (mostly empty) grid.
+template <int K, int CAP, typename IDX, int MODE>
 __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 nsrc,
                                                              const int *__restrict__ cell_start,
                                                              const double *__restrict__ sorted_xyz, int ndim,
@@ -947,9 +965,14 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                                                              IDX *__restrict__ idx_out,
                                                              double *__restrict__ dist_out,
                                                              int *__restrict__ fb_list, int *__restrict__ fb_count,
-                                                             int dbg_stop, int nsplit)
+                                                             int dbg_stop, int nsplit, int *__restrict__ down_list,
+                                                             int *__restrict__ down_count,
+                                                             const unsigned *__restrict__ strip_list,
+                                                             const int *__restrict__ strip_count)
 {
     static_assert(CAP <= 64, "rank mask is 64 bits");
+    constexpr bool WALK = MODE == 2;
+    if (MODE == 0) down_list = nullptr;
 #ifndef MM_STRIP_NB_SMALL   // tuning builds only
 #define MM_STRIP_NB_SMALL 32
 #endif
@@ -1005,17 +1028,27 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
     const int ncols = g.nx * g.ny;
     const int cols_per_xcd = (ncols + 7) / 8;
     const int nstrips = (g.nz + kStripZ - 1) / kStripZ;
-    const int xcd = blockIdx.x & 7;
+    // With strip_list (the denser levels of a graded cloud, whose grids are mostly empty) the workgroups
+    // walk the list of strips that hold targets -- entries in the encoding of blockIdx.x -- instead of
+    // being one workgroup per strip of the grid.
+    for (unsigned sidx = blockIdx.x;; sidx += gridDim.x) {
+    if (WALK) {
+        if (sidx >= (unsigned)*strip_count) break;
+        if (sidx != blockIdx.x) wave_sync();   // the previous strip's LDS is done with
+    }
+#define MM_NEXT_STRIP { if (!WALK) return; continue; }
+    const unsigned bid = WALK ? strip_list[sidx] : blockIdx.x;
+    const int xcd = bid & 7;
     // nsplit > 1 (many more targets than sources, e.g. the unique GLL points of a fine mesh over a
     // coarse one): nsplit waves per strip -- consecutive workgroups of one XCD -- share its targets
-    int m = blockIdx.x >> 3, part = 0;
+    int m = bid >> 3, part = 0;
     if (nsplit > 1) {
         part = m % nsplit;
         m = m / nsplit;
     }
     const int colm = m / nstrips;
     const int col = xcd * cols_per_xcd + colm;
-    if (colm >= cols_per_xcd || col >= ncols) return;
+    if (colm >= cols_per_xcd || col >= ncols) MM_NEXT_STRIP
     const int strip = m - colm * nstrips;
     const int cx = col / g.ny, cy = col - cx * g.ny;
     const int cz0 = strip * kStripZ, cz1 = min(cz0 + kStripZ, g.nz);
@@ -1044,7 +1077,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         t0 += part * chunk;
         tn = min(chunk, t1 - t0);
     }
-    if (tn <= 0) return;
+    if (tn <= 0) MM_NEXT_STRIP
     const double ox = g.lox + (double)cx * g.hx;
     const double oy = g.loy + (double)cy * g.hy;
     const double oz = g.loz + (double)cz0 * g.hz;
@@ -1123,10 +1156,20 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
         }
     }
     if (total > kStripTileCap || total < kout) {
-        // the whole strip goes to the generic kernel
-        for (int q = lane; q < tn; q += kWave)
-            fb_list[atomicAdd(fb_count, 1)] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
-        return;
+        // the whole strip goes to the next density level when it is too full for the tile and there is
+        // one, else to the generic kernel
+        // (the choice is made wave-uniform explicitly and each branch names its counter directly:
+        // `total` comes out of shuffles, and with a selected pointer the compiler does not combine the
+        // lanes' atomics into one per wave -- 21 ms of same-address atomics on a graded cloud)
+        const bool down = __builtin_amdgcn_readfirstlane((int)(total > kStripTileCap)) != 0 && down_list != nullptr;
+        if (down) {
+            for (int q = lane; q < tn; q += kWave)
+                down_list[atomicAdd(down_count, 1)] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+        } else {
+            for (int q = lane; q < tn; q += kWave)
+                fb_list[atomicAdd(fb_count, 1)] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+        }
+        MM_NEXT_STRIP
     }
     wave_sync();  // tile and layer table staged
     if (dbg_stop == 1) return;  // diagnostic builds only (MM_KNN_DBG_STOP): time the phases
@@ -1208,7 +1251,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
             width = 2.2f * r2 * (1.f / (float)kNB);
             scale = 1.f / width;
         }
-        bool hand_over = !(scale > 0.f && scale < INFINITY) || we - ws < kout || we - ws > kTileCap;
+        const bool too_dense = we - ws > kTileCap;   // the window alone is more than a round can take
+        bool hand_over = !(scale > 0.f && scale < INFINITY) || we - ws < kout || too_dense;
         if (!(scale > 0.f && scale < INFINITY)) scale = width = 1.f;
         wave_sync();  // counters cleared
 
@@ -1426,25 +1470,53 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
                     if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
                 }
             }
-            if (hand_over) fb_list[atomicAdd(fb_count, 1)] = (int)i;
+            if (MODE == 0 && hand_over) fb_list[atomicAdd(fb_count, 1)] = (int)i;
+        }
+        if (MODE != 0) {
+            // hand-overs of this round: one atomic per list and wave (with two lists to choose from
+            // the compiler no longer combines the lanes' atomics itself)
+            const bool push = valid && sl == 0 && hand_over;
+            const bool push_down = push && too_dense && down_list != nullptr;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long md = __ballot(push_down), mf = __ballot(push && !push_down);
+            if (md) {
+                const int first = __ffsll((long long)md) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(down_count, __popcll(md));
+                base = __shfl(base, first);
+                if (push_down) down_list[base + __popcll(md & lt)] = (int)i;
+            }
+            if (mf) {
+                const int first = __ffsll((long long)mf) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(fb_count, __popcll(mf));
+                base = __shfl(base, first);
+                if (push && !push_down) fb_list[base + __popcll(mf & lt)] = (int)i;
+            }
         }
         wave_sync();  // before the next round clears the counters
         if (dbg_stop == 8) return;
     }
+    if (!WALK) break;
+    }
+#undef MM_NEXT_STRIP
 }
 
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
 __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__restrict__ cell_of, i64 npts,
                                                                 const double *__restrict__ pts, int ndim,
                                                                 const int *__restrict__ start,
-                                                                double *__restrict__ tsorted)
+                                                                double *__restrict__ tsorted,
+                                                                const int *__restrict__ list,
+                                                                const int *__restrict__ list_count)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npts) return;
+    if (t >= (list ? (i64)*list_count : npts)) return;
     const int2 cr = cell_of[t];
     const i64 pos = (i64)start[cr.x] + cr.y;
-    store_record(tsorted + pos * kRec, pts[t * ndim], ndim > 1 ? pts[t * ndim + 1] : 0.0,
-                 ndim > 2 ? pts[t * ndim + 2] : 0.0, (int)t);
+    const i64 p = list ? (i64)list[t] : t;   // the record carries the target's own index
+    store_record(tsorted + pos * kRec, pts[p * ndim], ndim > 1 ? pts[p * ndim + 1] : 0.0,
+                 ndim > 2 ? pts[p * ndim + 2] : 0.0, (int)p);
 }
 
 template <int K, typename IDX>
@@ -1458,10 +1530,42 @@ void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g
                        list_count);
 }
 
+// Strips of a level that hold targets, as workgroup ids of knn_strip_kernel (nsplit parts each).
+__global__ __launch_bounds__(kBlock) void strips_with_targets_kernel(GridParams g, const int *__restrict__ tstart,
+                                                                     int nsplit, unsigned *__restrict__ list,
+                                                                     int *__restrict__ count)
+{
+    const int ncols = g.nx * g.ny;
+    const int cols_per_xcd = (ncols + 7) / 8;
+    const int nstrips = (g.nz + kStripZ - 1) / kStripZ;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool has = false;
+    unsigned m = 0, xcd = 0;
+    if (t < (i64)ncols * nstrips) {
+        const int col = (int)(t / nstrips), strip = (int)(t - (i64)col * nstrips);
+        const int cz0 = strip * kStripZ, cz1 = min(cz0 + kStripZ, g.nz);
+        has = tstart[col * g.nz + cz1] > tstart[col * g.nz + cz0];
+        xcd = (unsigned)(col / cols_per_xcd);
+        m = (unsigned)(col - (int)xcd * cols_per_xcd) * (unsigned)nstrips + (unsigned)strip;
+    }
+    const unsigned long long vote = __ballot(has);
+    if (!vote) return;
+    const int lane = threadIdx.x & 63;
+    const int first = __ffsll((long long)vote) - 1;
+    int base = 0;
+    if (lane == first) base = atomicAdd(count, __popcll(vote) * nsplit);
+    base = __shfl(base, first);
+    if (has) {
+        const int at = base + __popcll(vote & ((1ull << lane) - 1ull)) * nsplit;
+        for (int p = 0; p < nsplit; ++p) list[at + p] = ((m * (unsigned)nsplit + (unsigned)p) << 3) | xcd;
+    }
+}
+
 template <int K, typename IDX>
 void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
                  int kout, const int *tstart, const double *tsorted, IDX *idx, double *dist,
-                 int *fb_list, int *fb_count)
+                 int *fb_list, int *fb_count, int *down_list, int *down_count, bool record_stage,
+                 unsigned *strip_list, int *strip_count)
 {
 #ifndef MM_KNN_CAP_EXTRA_SMALL   // tuning builds only
 #define MM_KNN_CAP_EXTRA_SMALL 8
@@ -1475,7 +1579,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     // strips along z need a grid that is deep in z; flat and 2-D grids keep the cell kernel
     static const int force = getenv("MM_KNN_KERNEL") ? (strcmp(getenv("MM_KNN_KERNEL"), "strip") == 0 ? 1 : 2) : 0;
     const bool use_strip = force == 1 || (force == 0 && ix->dims[2] >= 6);
-    mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
+    if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     if (use_strip) {
         const i64 nstrips = (ix->dims[2] + kStripZ - 1) / kStripZ;
         i64 strip_grid = 8 * ((cols + 7) / 8) * nstrips;
@@ -1487,15 +1591,34 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         if (force_split > 0) nsplit = force_split;
         nsplit = nsplit < 1 ? 1 : (nsplit > kMaxSplit ? kMaxSplit : nsplit);
         while (nsplit > 1 && strip_grid * nsplit > (i64)0x7fffffff) --nsplit;
-        strip_grid *= nsplit;
-        hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX>), dim3((unsigned)strip_grid), dim3(kWave), 0, ctx->stream, g,
-                           ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist,
-                           fb_list, fb_count, dbg_stop, (int)nsplit);
+        if (strip_list) {
+            // a denser level: only the strips that hold targets, walked by a fixed number of workgroups
+            nsplit = 1;   // (the list holds at most one entry per target)
+            hipLaunchKernelGGL(strips_with_targets_kernel, dim3((unsigned)((cols * nstrips + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, ctx->stream, g, tstart, (int)nsplit, strip_list, strip_count);
+            i64 walkers = (npts + kStripGroups - 1) / kStripGroups;   // no more workgroups than rounds
+            if (walkers > 16384) walkers = 16384;
+            hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX, 2>), dim3((unsigned)walkers), dim3(kWave), 0, ctx->stream, g,
+                               ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist,
+                               fb_list, fb_count, dbg_stop, (int)nsplit, down_list, down_count, strip_list, strip_count);
+        } else {
+            strip_grid *= nsplit;
+            if (down_list)
+                hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX, 1>), dim3((unsigned)strip_grid), dim3(kWave), 0,
+                                   ctx->stream, g, ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart,
+                                   tsorted, idx, dist, fb_list, fb_count, dbg_stop, (int)nsplit, down_list, down_count,
+                                   (const unsigned *)nullptr, (const int *)nullptr);
+            else
+                hipLaunchKernelGGL((knn_strip_kernel<K, CAP, IDX, 0>), dim3((unsigned)strip_grid), dim3(kWave), 0,
+                                   ctx->stream, g, ix->nsrc, ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart,
+                                   tsorted, idx, dist, fb_list, fb_count, dbg_stop, (int)nsplit, (int *)nullptr,
+                                   (int *)nullptr, (const unsigned *)nullptr, (const int *)nullptr);
+        }
     } else {
         hipLaunchKernelGGL((knn_cell_kernel<K, CAP, IDX>), dim3((unsigned)cell_grid), dim3(kWave), 0, ctx->stream, g,
                            ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
     }
-    mm_stage_end(ctx, MM_STAGE_KNN_CELL);
+    if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
     launch_generic<K, IDX>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
 
@@ -1520,6 +1643,7 @@ GridParams params_of(const mm_knn_index *ix)
 void free_index(mm_knn_index *ix)
 {
     if (!ix) return;
+    free_index(ix->fine);
     if (!ix->borrowed) {
         if (ix->cell_start) (void)hipFree(ix->cell_start);
         if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
@@ -1541,9 +1665,12 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
     return MM_OK;
 }
 
-// Build without touching the stage timers (used by the fused pipeline too).
-int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers, const double *box_partial_d, int box_nblocks)
+// One grid over the sources, laid out for ~per_cell sources per cell: counting sort of the sources by
+// cell into 32-byte records.  With level_extra != null the share of sources in well-filled cells is
+// read back (while the scan and the scatter are still queued, so a uniform cloud pays no idle time
+// for it) and *level_extra = the number of denser levels the cloud asks for.
+static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
+                       bool use_context_buffers, int *level_extra, mm_knn_index **out)
 {
     *out = nullptr;
     mm_knn_index *ix = new (std::nothrow) mm_knn_index();
@@ -1552,44 +1679,7 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         return MM_ERR_ALLOC;
     }
     ix->nsrc = nsrc;
-    ix->ndim = (int)ndim;
-
-    // bounding box (one small synchronising readback; the build is a once-per-mesh step)
-    double box[6] = {0, 0, 0, 0, 0, 0};
-    if (nsrc > 0) {
-        const int nblocks = (int)((nsrc + kBlock - 1) / kBlock < 1024 ? (nsrc + kBlock - 1) / kBlock : 1024);
-        int rc = mm_scratch_begin(ctx, (size_t)nblocks * 6 * sizeof(double) + 6 * sizeof(double) + 1024);
-        if (rc != MM_OK) { delete ix; return rc; }
-        double *partial = (double *)mm_scratch_take(ctx, (size_t)nblocks * 6 * sizeof(double));
-        double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
-        if (box_partial_d) {
-            // the producer of the sources (the fused pipeline's centroid kernel) already left partials
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
-        } else {
-            hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
-                               (int)ndim, partial);
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
-        }
-        hipError_t e = hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            mm_set_error(MM_ERR_HIP, "bounding box: %s", hipGetErrorString(e));
-            delete ix;
-            return MM_ERR_HIP;
-        }
-    }
-    // grid resolution: ~per_cell sources per cell over the axes that have extent
-    // (MM_KNN_PER_CELL overrides the default, for tuning experiments only)
-    double per_cell = kDefaultPerCell;
-    if (const char *env = getenv("MM_KNN_PER_CELL")) {
-        const double v = atof(env);
-        if (v >= 0.25 && v <= 4096.0) per_cell = v;
-    }
-    int max_refine = kMaxRefine;
-    if (const char *env = getenv("MM_KNN_REFINE")) max_refine = atoi(env) < 0 ? 0 : (atoi(env) > 3 ? 3 : atoi(env));
-    double refine_share = kRefineShare, refine_cells = kRefineMaxCellsPerSource;
-    if (const char *env = getenv("MM_KNN_REFINE_SHARE")) refine_share = atof(env);
-    if (const char *env = getenv("MM_KNN_REFINE_CELLS")) refine_cells = atof(env);
+    ix->ndim = ndim;
     double ext[3] = {0, 0, 0};
     int live = 0;
     double vol = 1.0;
@@ -1601,14 +1691,6 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
             vol *= ext[a];
         }
     }
-    // A graded cloud (mesh refined towards a surface or a source region) puts most of its points
-    // into a few overfull cells of a grid sized for the mean density, and those cells fall off the
-    // tiled kernels.  The build therefore measures the share of sources in overfull cells and, when
-    // it is large, lays the grid out again with cells of half the edge -- sized for where the
-    // points are; the sparse remainder is what the ring-expansion kernel is for.  The statistic is
-    // read back while the scan and the scatter of the same attempt are still queued, so a uniform
-    // cloud pays no idle time for it.
-    for (int attempt = 0;; ++attempt) {
     const double want_cells = nsrc > 0 ? (double)nsrc / per_cell : 1.0;
     const double edge = live > 0 ? pow(vol / (want_cells > 1.0 ? want_cells : 1.0), 1.0 / live) : 1.0;
     i64 ncells = 1;
@@ -1628,13 +1710,6 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     const GridParams g = params_of(ix);
 
     hipError_t e = hipSuccess;
-    if (attempt > 0 && !use_context_buffers) {
-        (void)hipStreamSynchronize(ctx->stream);
-        if (ix->cell_start) (void)hipFree(ix->cell_start);
-        if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
-        ix->cell_start = nullptr;
-        ix->sorted_xyz = nullptr;
-    }
     if (use_context_buffers) {
         ix->borrowed = true;
         int brc = mm_buffer_get(ctx, MM_BUF_CELL_START, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
@@ -1673,17 +1748,18 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     if (e != hipSuccess) { mm_set_error(MM_ERR_HIP, "memset: %s", hipGetErrorString(e)); free_index(ix); return MM_ERR_HIP; }
     const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
     if (nsrc > 0)
-        hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim, g,
-                           cell_of, counts);
-    const bool may_refine = attempt < max_refine && nsrc >= kRefineMinSources && live > 0 &&
-                            (double)ncells * 8.0 <= refine_cells * (double)nsrc;
-    if (may_refine) {
+        hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
+                           counts, (const int *)nullptr, (const int *)nullptr);
+    const bool want_stat = level_extra != nullptr && nsrc >= kLevelMinSources && live > 0;
+    if (level_extra) *level_extra = 0;
+    if (want_stat) {
         i64 *stat = ctx->d_counters + kStatSlot;
-        e = hipMemsetAsync(stat, 0, sizeof(i64), ctx->stream);
+        e = hipMemsetAsync(stat, 0, (kMaxLevels - 1) * sizeof(i64), ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(overfull_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+            hipLaunchKernelGGL(level_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                                ctx->stream, counts, ncells, (unsigned long long *)stat);
-            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, (kMaxLevels - 1) * sizeof(i64), hipMemcpyDeviceToHost,
+                               ctx->stream);
         }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
         if (e != hipSuccess) {
@@ -1697,30 +1773,95 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                        ix->cell_start);
     if (nsrc > 0)
-        hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim,
-                           cell_of, ix->cell_start, ix->sorted_xyz);
+        hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, cell_of,
+                           ix->cell_start, ix->sorted_xyz);
     e = hipGetLastError();
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "kNN build launch: %s", hipGetErrorString(e));
         free_index(ix);
         return MM_ERR_HIP;
     }
-    if (!may_refine) break;
-    e = hipEventSynchronize(ctx->ev_misc);
-    if (e != hipSuccess) {
-        mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
-        free_index(ix);
-        return MM_ERR_HIP;
-    }
-    const i64 overfull = ctx->h_counters[kStatSlot];
-    if (getenv("MM_KNN_DEBUG"))
-        fprintf(stderr, "[mm_knn] build attempt %d: %lld cells, %.1f %% of the sources in overfull cells\n", attempt,
-                (long long)ncells, 100.0 * (double)overfull / (double)nsrc);
-    if ((double)overfull <= refine_share * (double)nsrc) break;
-    per_cell *= 0.125;
-    if (getenv("MM_KNN_DEBUG")) fprintf(stderr, "[mm_knn] laying the grid out again at %.3g sources per cell\n", per_cell);
+    if (want_stat) {
+        e = hipEventSynchronize(ctx->ev_misc);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
+            free_index(ix);
+            return MM_ERR_HIP;
+        }
+        // bit l-1 set: level l is wanted (band mass = difference of the cumulative shares)
+        for (int b = 0; b < kMaxLevels - 1; ++b) {
+            const double above = (double)ctx->h_counters[kStatSlot + b];
+            const double next = b + 1 < kMaxLevels - 1 ? (double)ctx->h_counters[kStatSlot + b + 1] : 0.0;
+            if (above - next > kLevelShare * (double)nsrc) *level_extra |= 1 << b;
+        }
+        if (getenv("MM_KNN_DEBUG")) {
+            fprintf(stderr, "[mm_knn] build: %lld cells; %% of the sources in cells above", (long long)ncells);
+            for (int b = 0; b < kMaxLevels - 1; ++b)
+                fprintf(stderr, " %d: %.1f", kLevelCount[b], 100.0 * ctx->h_counters[kStatSlot + b] / (double)nsrc);
+            fprintf(stderr, " -> level mask 0x%x\n", *level_extra);
+        }
     }
     *out = ix;
+    return MM_OK;
+}
+
+// Build without touching the stage timers (used by the fused pipeline too).
+int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks)
+{
+    *out = nullptr;
+    // bounding box (one small synchronising readback; the build is a once-per-mesh step)
+    double box[6] = {0, 0, 0, 0, 0, 0};
+    if (nsrc > 0) {
+        const int nblocks = (int)((nsrc + kBlock - 1) / kBlock < 1024 ? (nsrc + kBlock - 1) / kBlock : 1024);
+        int rc = mm_scratch_begin(ctx, (size_t)nblocks * 6 * sizeof(double) + 6 * sizeof(double) + 1024);
+        if (rc != MM_OK) return rc;
+        double *partial = (double *)mm_scratch_take(ctx, (size_t)nblocks * 6 * sizeof(double));
+        double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
+        if (box_partial_d) {
+            // the producer of the sources (the fused pipeline's centroid kernel) already left partials
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
+        } else {
+            hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
+                               (int)ndim, partial);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
+        }
+        hipError_t e = hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_HIP, "bounding box: %s", hipGetErrorString(e));
+            return MM_ERR_HIP;
+        }
+    }
+    // grid resolution: ~per_cell sources per cell over the axes that have extent
+    // (MM_KNN_PER_CELL overrides the default, for tuning experiments only)
+    double per_cell = kDefaultPerCell;
+    if (const char *env = getenv("MM_KNN_PER_CELL")) {
+        const double v = atof(env);
+        if (v >= 0.25 && v <= 4096.0) per_cell = v;
+    }
+    int max_levels = kMaxLevels;
+    if (const char *env = getenv("MM_KNN_LEVELS")) max_levels = atoi(env) < 1 ? 1 : (atoi(env) > kMaxLevels ? kMaxLevels : atoi(env));
+    int extra = 0;
+    mm_knn_index *head = nullptr;
+    int rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, max_levels > 1 ? &extra : nullptr,
+                         &head);
+    if (rc != MM_OK) return rc;
+    mm_knn_index *tail = head;
+    for (int l = 1; l < max_levels; ++l) {
+        per_cell /= kLevelRatio;
+        if (!(extra & (1 << (l - 1)))) continue;
+        if ((double)nsrc / per_cell > (double)kLevelMaxCells) break;
+        mm_knn_index *lvl = nullptr;
+        rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, /*use_context_buffers=*/false, nullptr, &lvl);
+        if (rc != MM_OK) {
+            free_index(head);
+            return rc;
+        }
+        tail->fine = lvl;
+        tail = lvl;
+    }
+    *out = head;
     return MM_OK;
 }
 
@@ -1739,53 +1880,78 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         MM_HIP_CHECK(hipGetLastError());
         return MM_OK;
     }
-    // scratch: visiting order of the targets (counting sort by cell) + straggler queue
-    const i64 ncells = ix->ncells;
-    const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
-    const size_t need = mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
-                        mm_round256((size_t)npts * sizeof(int)) +               // fb_list
-                        mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
-                        2 * mm_round256((size_t)(ncells + 1) * sizeof(int)) +   // counts, start
-                        mm_round256((size_t)ntiles * sizeof(int)) + 1024;
+    // One pass per density level: the level's share of the targets is counting-sorted by its cells and
+    // visited strip by strip; targets whose strip is too full for the tile go down to the next level
+    // (a device-side list), everything else the level cannot place goes to its generic kernel.
+    int nlevels = 0;
+    size_t need = 1024;
+    for (const mm_knn_index *l = ix; l; l = l->fine) {
+        const i64 nc = l->ncells;
+        const int nt = (int)((nc + kScanTile - 1) / kScanTile);
+        need += mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
+                mm_round256((size_t)npts * sizeof(int)) +               // stragglers of this level
+                (l->fine ? mm_round256((size_t)npts * sizeof(int)) : 0) +   // targets passed down
+                (l != ix ? mm_round256((size_t)npts * sizeof(unsigned)) : 0) +   // strips that hold targets
+                mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
+                2 * mm_round256((size_t)(nc + 1) * sizeof(int)) +       // counts, start
+                mm_round256((size_t)nt * sizeof(int)) + 256;
+        ++nlevels;
+    }
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) return rc;
-    int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
-    int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
-    int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
-    int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
-    int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
-    int *fb_count = (int *)mm_scratch_take(ctx, 256);
-    double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
-    if (!tsorted || !cell_of || !fb_list || !counts || !start || !tile_sums || !fb_count) {
-        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
-        return MM_ERR_ALLOC;
-    }
-    MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
-    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, ix->ndim, g, cell_of,
-                       counts);
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
-    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
-    hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, ix->ndim,
-                       start, tsorted);
-
-    if (k <= 1) launch_fast<1, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 2) launch_fast<2, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 4) launch_fast<4, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 8) launch_fast<8, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 16) launch_fast<16, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 20) launch_fast<20, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else if (k <= 25) launch_fast<25, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    else launch_fast<32, IDX>(ctx, ix, g, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count);
-    MM_HIP_CHECK(hipGetLastError());
-    if (getenv("MM_KNN_DEBUG")) {
-        int h = 0;
-        MM_HIP_CHECK(hipMemcpyAsync(&h, fb_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[mm_knn] %d of %lld targets handed to the generic kernel (%.2f %%)\n", h, (long long)npts,
-                100.0 * h / (double)npts);
+    const int *list = nullptr, *list_count = nullptr;   // level 0: every target
+    int level = 0;
+    for (const mm_knn_index *l = ix; l; l = l->fine, ++level) {
+        const GridParams gl = params_of(l);
+        const i64 ncells = l->ncells;
+        const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
+        int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
+        int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+        int *down_list = l->fine ? (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int)) : nullptr;
+        int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+        int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+        int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
+        int *fb_count = (int *)mm_scratch_take(ctx, 256);
+        int *down_count = fb_count + 1, *strip_count = fb_count + 2;
+        unsigned *strip_list = level > 0 ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
+        double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
+        if (!tsorted || !cell_of || !fb_list || !counts || !start || !tile_sums || !fb_count || (l->fine && !down_list) ||
+            (level > 0 && !strip_list)) {
+            mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+            return MM_ERR_ALLOC;
+        }
+        MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
+        MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
+                           counts, list, list_count);
+        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
+        hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
+        hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim,
+                           start, tsorted, list, list_count);
+#define MM_FAST(KK)                                                                                                  \
+    launch_fast<KK, IDX>(ctx, l, gl, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count, down_list, \
+                         down_count, level == 0, strip_list, strip_count)
+        if (k <= 1) MM_FAST(1);
+        else if (k <= 2) MM_FAST(2);
+        else if (k <= 4) MM_FAST(4);
+        else if (k <= 8) MM_FAST(8);
+        else if (k <= 16) MM_FAST(16);
+        else if (k <= 20) MM_FAST(20);
+        else if (k <= 25) MM_FAST(25);
+        else MM_FAST(32);
+#undef MM_FAST
+        MM_HIP_CHECK(hipGetLastError());
+        if (getenv("MM_KNN_DEBUG")) {
+            int h[2] = {0, 0};
+            MM_HIP_CHECK(hipMemcpyAsync(h, fb_count, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "[mm_knn] level %d of %d (%lld cells): %d targets handed to the generic kernel, %d passed down "
+                            "(%lld targets in the query)\n", level, nlevels, (long long)ncells, h[0], h[1], (long long)npts);
+        }
+        list = down_list;
+        list_count = down_count;
     }
     return MM_OK;
 }

@@ -521,21 +521,34 @@ def test_knn_list_capacities_that_are_not_a_multiple_of_four(ctx, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("power", [2.0, 3.0])
-def test_knn_graded_cloud_relaid_grid(ctx, power, monkeypatch):
-    # coordinates = uniform^p: most sources sit in a few cells of a grid sized for the mean density,
-    # so the build lays the grid out a second time with finer cells (mm_knn.hip, "adaptive grid").
-    # Same lists from the relaid grid, from the plain one and from the k-d tree.
+@pytest.mark.parametrize("power,k", [(1.5, 20), (2.0, 8), (3.0, 20)])
+def test_knn_graded_cloud_density_levels(ctx, power, k, monkeypatch):
+    # coordinates = uniform^p: the density varies by orders of magnitude, so the build adds grids laid
+    # out for denser regions and targets whose strip overflows the tile are passed down a level
+    # (mm_knn.hip, "density levels").  Same lists with the levels, with one grid only, and from the
+    # k-d tree.
     rng = np.random.default_rng(17)
     src = rng.uniform(size=(150_000, 3)) ** power
     q = rng.uniform(size=(40_000, 3)) ** power
-    ref, dref = O.knn_ckdtree(src, q, 20, workers=-1)
-    for refine in ("1", "0"):
-        monkeypatch.setenv("MM_KNN_REFINE", refine)
+    ref, dref = O.knn_ckdtree(src, q, k, workers=-1)
+    for levels in ("5", "1"):
+        monkeypatch.setenv("MM_KNN_LEVELS", levels)
         tree = ctx.knn_build(src)
-        idx, dist = tree.query(q, 20, want_dist=True)
-        assert np.array_equal(idx.numpy().reshape(len(q), 20), ref.reshape(len(q), 20))
-        np.testing.assert_allclose(dist.numpy().reshape(len(q), 20), dref.reshape(len(q), 20), rtol=1e-12, atol=0)
+        idx, dist = tree.query(q, k, want_dist=True)
+        assert np.array_equal(idx.numpy().reshape(len(q), k), ref.reshape(len(q), k))
+        np.testing.assert_allclose(dist.numpy().reshape(len(q), k), dref.reshape(len(q), k), rtol=1e-12, atol=0)
+
+
+def test_knn_two_densities_like_a_locally_refined_mesh(ctx):
+    # a coarse background and a region refined 3x per axis (27x the density): neither fits a grid laid out
+    # for the mean; with density levels both are served by the tiled kernel
+    rng = np.random.default_rng(23)
+    coarse = rng.uniform(size=(120_000, 3))
+    fine = 0.35 + 0.2 * rng.uniform(size=(120_000, 3))
+    src = np.concatenate([coarse, fine])
+    q = np.concatenate([rng.uniform(size=(30_000, 3)), 0.35 + 0.2 * rng.uniform(size=(30_000, 3))])
+    for k in (8, 20):
+        assert np.array_equal(ctx.knn_build(src).query(q, k).numpy(), O.knn_ckdtree(src, q, k, workers=-1)[0])
 
 
 @pytest.mark.gpu
