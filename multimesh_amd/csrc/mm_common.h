@@ -48,7 +48,8 @@ enum mm_buffer_slot {
     MM_BUF_SORTED_XYZ,
     MM_BUF_NN_FULL,
     MM_BUF_BOX_PARTIAL,
-    MM_BUF_COUNT
+    MM_BUF_LEVELS,                        // density levels of the kNN grid: {cell_start, sorted_xyz} per level
+    MM_BUF_COUNT = MM_BUF_LEVELS + 2 * 8
 };
 
 struct mm_context {

@@ -1670,8 +1670,11 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
 // read back (while the scan and the scatter are still queued, so a uniform cloud pays no idle time
 // for it) and *level_extra = the number of denser levels the cloud asks for.
 static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
-                       bool use_context_buffers, int *level_extra, mm_knn_index **out)
+                       bool use_context_buffers, int level, int *level_extra, mm_knn_index **out)
 {
+    static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
+    const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
+    const int slot_xyz = level == 0 ? (int)MM_BUF_SORTED_XYZ : (int)MM_BUF_LEVELS + 2 * (level - 1) + 1;
     *out = nullptr;
     mm_knn_index *ix = new (std::nothrow) mm_knn_index();
     if (!ix) {
@@ -1712,9 +1715,9 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     hipError_t e = hipSuccess;
     if (use_context_buffers) {
         ix->borrowed = true;
-        int brc = mm_buffer_get(ctx, MM_BUF_CELL_START, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
+        int brc = mm_buffer_get(ctx, slot_cells, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
         if (brc == MM_OK)
-            brc = mm_buffer_get(ctx, MM_BUF_SORTED_XYZ, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double),
+            brc = mm_buffer_get(ctx, slot_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double),
                                 (void **)&ix->sorted_xyz);
         if (brc != MM_OK) {
             free_index(ix);
@@ -1844,8 +1847,8 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     if (const char *env = getenv("MM_KNN_LEVELS")) max_levels = atoi(env) < 1 ? 1 : (atoi(env) > kMaxLevels ? kMaxLevels : atoi(env));
     int extra = 0;
     mm_knn_index *head = nullptr;
-    int rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, max_levels > 1 ? &extra : nullptr,
-                         &head);
+    int rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, 0,
+                         max_levels > 1 ? &extra : nullptr, &head);
     if (rc != MM_OK) return rc;
     mm_knn_index *tail = head;
     for (int l = 1; l < max_levels; ++l) {
@@ -1853,7 +1856,7 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         if (!(extra & (1 << (l - 1)))) continue;
         if ((double)nsrc / per_cell > (double)kLevelMaxCells) break;
         mm_knn_index *lvl = nullptr;
-        rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, /*use_context_buffers=*/false, nullptr, &lvl);
+        rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, l, nullptr, &lvl);
         if (rc != MM_OK) {
             free_index(head);
             return rc;

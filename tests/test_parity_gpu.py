@@ -322,6 +322,32 @@ def test_cfg3_10M_to_10M_vector_field(ctx):
     _full_size_check(ctx, 216, 216, 3, sample=20_000)
 
 
+def test_graded_meshes_through_the_pipeline(ctx):
+    # meshes refined towards a corner (node coordinates u -> u^2.2 per axis: element sizes span three
+    # orders of magnitude, so the centroid cloud needs several density levels), source and target of
+    # different resolution; lazy and eager lists against cKDTree + the oracle
+    def warp(p):
+        return p ** 2.2
+
+    pa, ca = synth.hex_mesh(61, seed=1, jitter=0.1)
+    pb, _ = synth.hex_mesh(75, seed=7, jitter=0.1)
+    pa, pb = warp(pa), warp(pb)
+    fields = synth.vector_field(pa)[:2]
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+    vals_o = O.gather(fields, enc_o, w_o)
+    for lazy in (True, False):
+        ctx.set_lazy_lists(lazy)
+        try:
+            vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+            v2, nf2 = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+        finally:
+            ctx.set_lazy_lists(True)
+        assert nf == nf_o == nf2
+        assert np.array_equal(enc.numpy(), enc_o) and np.array_equal(w.numpy(), w_o)
+        assert np.array_equal(vals.numpy(), vals_o) and np.array_equal(v2.numpy(), vals_o)
+
+
 # ------------------------------------------------------------------------------- A10 GLL (parity unpinned)
 @pytest.mark.parametrize("order,dim", [(o, d) for o in (1, 2, 4) for d in (2, 3)])
 def test_gll_locate_and_gather_equal_the_oracle(ctx, order, dim):
