@@ -45,6 +45,7 @@ constexpr int kLevelCount[kMaxLevels - 1] = {15, 19, 38, 77, 154, 307, 614, 1229
 constexpr double kLevelShare = 0.02;   // of the sources, in the band of level-0 cell counts a level serves
 constexpr i64 kLevelMinSources = 4096;
 constexpr i64 kLevelMaxCells = (i64)1 << 27;
+constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a denser level above this home-cell count
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
@@ -471,6 +472,42 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
         knn_query_one<K, IDX>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
                          list ? (i64)list[q] : q);
+}
+
+// List mode over the density levels of a graded cloud: every listed target is searched in the first
+// (coarsest) grid whose home cell holds at most keep_max sources -- the kernel scans whole cells -- or
+// in the last one.  One launch for all levels (one tail of slow lanes instead of one per level).
+struct LevelTable {
+    int n;
+    GridParams g[kMaxLevels];
+    const int *cell_start[kMaxLevels];
+    const double *sorted_xyz[kMaxLevels];
+};
+
+template <int K, typename IDX>
+__global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv, i64 nsrc,
+                                                                  const double *__restrict__ pts, int ndim, int kout,
+                                                                  IDX *__restrict__ idx_out,
+                                                                  const int *__restrict__ list,
+                                                                  const int *__restrict__ list_count, int keep_max)
+{
+    const i64 total = *list_count;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const i64 i = list[q];
+        const double x = pts[i * ndim];
+        const double y = ndim > 1 ? pts[i * ndim + 1] : 0.0;
+        const double z = ndim > 2 ? pts[i * ndim + 2] : 0.0;
+        int l = 0;
+        for (; l < lv.n - 1; ++l) {
+            const GridParams &g = lv.g[l];
+            const int c = (cell_coord(x, g.lox, g.ihx, g.nx) * g.ny + cell_coord(y, g.loy, g.ihy, g.ny)) * g.nz +
+                          cell_coord(z, g.loz, g.ihz, g.nz);
+            if (lv.cell_start[l][c + 1] - lv.cell_start[l][c] <= keep_max) break;
+        }
+        knn_query_one<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], pts, ndim, kout, idx_out,
+                              (double *)nullptr, i);
+    }
 }
 
 // ---- fast path: one wave per grid cell, sources staged in LDS --------------------------------
@@ -1963,14 +2000,32 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
                            int *idx_d, const int *list, const int *list_count)
 {
     if (npts == 0 || k == 0) return MM_OK;
-    const GridParams g = params_of(ix);
     const int kout = (int)k;
-    if (k <= 8) launch_generic<8, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
-    else if (k <= 16) launch_generic<16, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
-    else if (k <= 20) launch_generic<20, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
-    else if (k <= 32) launch_generic<32, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
-    else if (k <= 40) launch_generic<40, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
-    else launch_generic<MM_KNN_MAX_K, int>(ctx, ix, g, pts_d, npts, kout, idx_d, nullptr, list, list_count);
+    LevelTable lv;
+    lv.n = 0;
+    for (const mm_knn_index *l = ix; l && lv.n < kMaxLevels; l = l->fine) {
+        lv.g[lv.n] = params_of(l);
+        lv.cell_start[lv.n] = l->cell_start;
+        lv.sorted_xyz[lv.n] = l->sorted_xyz;
+        ++lv.n;
+    }
+    i64 grid = (npts + kBlock - 1) / kBlock;
+    if (grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
+#define MM_LIST(KK)                                                                                                  \
+    do {                                                                                                             \
+        if (lv.n > 1)                                                                                                \
+            hipLaunchKernelGGL((knn_query_levels_kernel<KK, int>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv, \
+                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, list, list_count, kListKeepMax);             \
+        else                                                                                                         \
+            launch_generic<KK, int>(ctx, ix, lv.g[0], pts_d, npts, kout, idx_d, nullptr, list, list_count);          \
+    } while (0)
+    if (k <= 8) MM_LIST(8);
+    else if (k <= 16) MM_LIST(16);
+    else if (k <= 20) MM_LIST(20);
+    else if (k <= 32) MM_LIST(32);
+    else if (k <= 40) MM_LIST(40);
+    else MM_LIST(MM_KNN_MAX_K);
+#undef MM_LIST
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }

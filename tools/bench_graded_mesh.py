@@ -13,7 +13,8 @@ ctx.set_profiling(True)
 out = {}
 pa0, ca = synth.hex_mesh(n, seed=1, jitter=0.1)
 pb0, _ = synth.hex_mesh(n, seed=7, jitter=0.1)
-for power in (1.0, 1.5, 2.2):
+powers = [float(a) for a in sys.argv[2:]] or [1.0, 1.5, 2.2]
+for power in powers:
     pa, pb = pa0 ** power, pb0 ** power
     d_nodes, d_conn, d_pts = ctx.to_device(pa), ctx.to_device(ca), ctx.to_device(pb)
     d_f = ctx.to_device(synth.vector_field(pa)[:1])
