@@ -475,8 +475,8 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
 }
 
 // List mode over the density levels of a graded cloud: every listed target is searched in the first
-// (coarsest) grid whose home cell holds at most keep_max sources -- the kernel scans whole cells -- or
-// in the last one.  One launch for all levels (one tail of slow lanes instead of one per level).
+// (coarsest) grid whose 3x3x3 block around the home cell holds at most 27 keep_max sources -- the kernel
+// scans whole cells -- or in the last one.  One launch for all levels (one tail of slow lanes instead of one per level).
 struct LevelTable {
     int n;
     GridParams g[kMaxLevels];
@@ -488,6 +488,7 @@ template <int K, typename IDX>
 __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv, i64 nsrc,
                                                                   const double *__restrict__ pts, int ndim, int kout,
                                                                   IDX *__restrict__ idx_out,
+                                                                  double *__restrict__ dist_out,
                                                                   const int *__restrict__ list,
                                                                   const int *__restrict__ list_count, int keep_max)
 {
@@ -500,13 +501,21 @@ __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv,
         const double z = ndim > 2 ? pts[i * ndim + 2] : 0.0;
         int l = 0;
         for (; l < lv.n - 1; ++l) {
+            // sources in the 3x3x3 block around the home cell (nine runs along z): what the search
+            // scans at least
             const GridParams &g = lv.g[l];
-            const int c = (cell_coord(x, g.lox, g.ihx, g.nx) * g.ny + cell_coord(y, g.loy, g.ihy, g.ny)) * g.nz +
-                          cell_coord(z, g.loz, g.ihz, g.nz);
-            if (lv.cell_start[l][c + 1] - lv.cell_start[l][c] <= keep_max) break;
+            const int cx = cell_coord(x, g.lox, g.ihx, g.nx), cy = cell_coord(y, g.loy, g.ihy, g.ny);
+            const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
+            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+            int block = 0;
+            for (int ix = max(cx - 1, 0); ix <= min(cx + 1, g.nx - 1); ++ix)
+                for (int iy = max(cy - 1, 0); iy <= min(cy + 1, g.ny - 1); ++iy) {
+                    const int c = (ix * g.ny + iy) * g.nz;
+                    block += lv.cell_start[l][c + z1 + 1] - lv.cell_start[l][c + z0];
+                }
+            if (block <= 27 * keep_max) break;
         }
-        knn_query_one<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], pts, ndim, kout, idx_out,
-                              (double *)nullptr, i);
+        knn_query_one<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], pts, ndim, kout, idx_out, dist_out, i);
     }
 }
 
@@ -1656,7 +1665,6 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
                            ix->nsrc, ix->cell_start, ix->sorted_xyz, pts, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count, dbg_stop);
     }
     if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
-    launch_generic<K, IDX>(ctx, ix, g, pts, npts, kout, idx, dist, fb_list, fb_count);
 }
 
 GridParams params_of(const mm_knn_index *ix)
@@ -1929,7 +1937,6 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         const i64 nc = l->ncells;
         const int nt = (int)((nc + kScanTile - 1) / kScanTile);
         need += mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
-                mm_round256((size_t)npts * sizeof(int)) +               // stragglers of this level
                 (l->fine ? mm_round256((size_t)npts * sizeof(int)) : 0) +   // targets passed down
                 (l != ix ? mm_round256((size_t)npts * sizeof(unsigned)) : 0) +   // strips that hold targets
                 mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
@@ -1937,8 +1944,16 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                 mm_round256((size_t)nt * sizeof(int)) + 256;
         ++nlevels;
     }
+    need += mm_round256((size_t)npts * sizeof(int)) + 256;           // stragglers of all levels (one list)
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) return rc;
+    int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int *fb_count = (int *)mm_scratch_take(ctx, 256);
+    if (!fb_list || !fb_count) {
+        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+        return MM_ERR_ALLOC;
+    }
+    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
     const int *list = nullptr, *list_count = nullptr;   // level 0: every target
     int level = 0;
@@ -1947,22 +1962,21 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         const i64 ncells = l->ncells;
         const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
         int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
-        int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
         int *down_list = l->fine ? (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int)) : nullptr;
         int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
-        int *fb_count = (int *)mm_scratch_take(ctx, 256);
-        int *down_count = fb_count + 1, *strip_count = fb_count + 2;
+        int *down_count = (int *)mm_scratch_take(ctx, 256);
+        int *strip_count = down_count ? down_count + 1 : nullptr;
         unsigned *strip_list = level > 0 ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
         double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
-        if (!tsorted || !cell_of || !fb_list || !counts || !start || !tile_sums || !fb_count || (l->fine && !down_list) ||
+        if (!tsorted || !cell_of || !counts || !start || !tile_sums || !down_count || (l->fine && !down_list) ||
             (level > 0 && !strip_list)) {
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
         MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
-        MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), ctx->stream));
+        MM_HIP_CHECK(hipMemsetAsync(down_count, 0, 2 * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
@@ -1985,14 +1999,44 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         MM_HIP_CHECK(hipGetLastError());
         if (getenv("MM_KNN_DEBUG")) {
             int h[2] = {0, 0};
-            MM_HIP_CHECK(hipMemcpyAsync(h, fb_count, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MM_HIP_CHECK(hipMemcpyAsync(h, fb_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MM_HIP_CHECK(hipMemcpyAsync(h + 1, down_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            fprintf(stderr, "[mm_knn] level %d of %d (%lld cells): %d targets handed to the generic kernel, %d passed down "
+            fprintf(stderr, "[mm_knn] level %d of %d (%lld cells): %d targets for the generic kernel so far, %d passed down "
                             "(%lld targets in the query)\n", level, nlevels, (long long)ncells, h[0], h[1], (long long)npts);
         }
         list = down_list;
         list_count = down_count;
     }
+    // what no level could place: the generic kernel, once, every target in the grid that suits its home cell
+    LevelTable lv;
+    lv.n = 0;
+    for (const mm_knn_index *l = ix; l && lv.n < kMaxLevels; l = l->fine) {
+        lv.g[lv.n] = params_of(l);
+        lv.cell_start[lv.n] = l->cell_start;
+        lv.sorted_xyz[lv.n] = l->sorted_xyz;
+        ++lv.n;
+    }
+    i64 ggrid = (npts + kBlock - 1) / kBlock;
+    if (ggrid > 4096) ggrid = 4096;
+#define MM_GENERIC(KK)                                                                                               \
+    do {                                                                                                             \
+        if (lv.n > 1)                                                                                                \
+            hipLaunchKernelGGL((knn_query_levels_kernel<KK, IDX>), dim3((unsigned)ggrid), dim3(kBlock), 0, ctx->stream, lv, \
+                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax);     \
+        else                                                                                                         \
+            launch_generic<KK, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, fb_list, fb_count);                \
+    } while (0)
+    if (k <= 1) MM_GENERIC(1);
+    else if (k <= 2) MM_GENERIC(2);
+    else if (k <= 4) MM_GENERIC(4);
+    else if (k <= 8) MM_GENERIC(8);
+    else if (k <= 16) MM_GENERIC(16);
+    else if (k <= 20) MM_GENERIC(20);
+    else if (k <= 25) MM_GENERIC(25);
+    else MM_GENERIC(32);
+#undef MM_GENERIC
+    MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }
 
@@ -2015,7 +2059,8 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
     do {                                                                                                             \
         if (lv.n > 1)                                                                                                \
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, int>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv, \
-                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, list, list_count, kListKeepMax);             \
+                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, (double *)nullptr, list, list_count,   \
+                               kListKeepMax);                                                                \
         else                                                                                                         \
             launch_generic<KK, int>(ctx, ix, lv.g[0], pts_d, npts, kout, idx_d, nullptr, list, list_count);          \
     } while (0)
