@@ -490,12 +490,13 @@ __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv,
                                                                   IDX *__restrict__ idx_out,
                                                                   double *__restrict__ dist_out,
                                                                   const int *__restrict__ list,
-                                                                  const int *__restrict__ list_count, int keep_max)
+                                                                  const int *__restrict__ list_count, int keep_max,
+                                                                  i64 npts)
 {
-    const i64 total = *list_count;
+    const i64 total = list ? (i64)*list_count : npts;   // no list: every target (long lists, k > 32)
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        const i64 i = list[q];
+        const i64 i = list ? (i64)list[q] : q;
         const double x = pts[i * ndim];
         const double y = ndim > 1 ? pts[i * ndim + 1] : 0.0;
         const double z = ndim > 2 ? pts[i * ndim + 2] : 0.0;
@@ -1922,9 +1923,31 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     const GridParams g = params_of(ix);
     const int kout = (int)k;
     if (k > 32) {
-        // long lists: generic ring-expansion kernel for every target
-        if (k <= 40) launch_generic<40, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
-        else launch_generic<MM_KNN_MAX_K, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        // long lists: generic ring-expansion kernel for every target (in the grid that suits it, when
+        // the cloud has density levels)
+        if (ix->fine) {
+            LevelTable lv;
+            lv.n = 0;
+            for (const mm_knn_index *l = ix; l && lv.n < kMaxLevels; l = l->fine) {
+                lv.g[lv.n] = params_of(l);
+                lv.cell_start[lv.n] = l->cell_start;
+                lv.sorted_xyz[lv.n] = l->sorted_xyz;
+                ++lv.n;
+            }
+            const dim3 grid((unsigned)((npts + kBlock - 1) / kBlock)), block(kBlock);
+            if (k <= 40)
+                hipLaunchKernelGGL((knn_query_levels_kernel<40, IDX>), grid, block, 0, ctx->stream, lv, ix->nsrc, pts_d,
+                                   ix->ndim, kout, idx_d, dist_d, (const int *)nullptr, (const int *)nullptr,
+                                   kListKeepMax, npts);
+            else
+                hipLaunchKernelGGL((knn_query_levels_kernel<MM_KNN_MAX_K, IDX>), grid, block, 0, ctx->stream, lv, ix->nsrc,
+                                   pts_d, ix->ndim, kout, idx_d, dist_d, (const int *)nullptr, (const int *)nullptr,
+                                   kListKeepMax, npts);
+        } else if (k <= 40) {
+            launch_generic<40, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        } else {
+            launch_generic<MM_KNN_MAX_K, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
+        }
         MM_HIP_CHECK(hipGetLastError());
         return MM_OK;
     }
@@ -2023,7 +2046,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     do {                                                                                                             \
         if (lv.n > 1)                                                                                                \
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, IDX>), dim3((unsigned)ggrid), dim3(kBlock), 0, ctx->stream, lv, \
-                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax);     \
+                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax,     \
+                               npts);                                                                       \
         else                                                                                                         \
             launch_generic<KK, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, fb_list, fb_count);                \
     } while (0)
@@ -2060,7 +2084,7 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
         if (lv.n > 1)                                                                                                \
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, int>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv, \
                                ix->nsrc, pts_d, ix->ndim, kout, idx_d, (double *)nullptr, list, list_count,   \
-                               kListKeepMax);                                                                \
+                               kListKeepMax, npts);                                                          \
         else                                                                                                         \
             launch_generic<KK, int>(ctx, ix, lv.g[0], pts_d, npts, kout, idx_d, nullptr, list, list_count);          \
     } while (0)

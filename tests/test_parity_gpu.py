@@ -547,7 +547,7 @@ def test_knn_list_capacities_that_are_not_a_multiple_of_four(ctx, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("power,k", [(1.5, 20), (2.0, 8), (3.0, 20)])
+@pytest.mark.parametrize("power,k", [(1.5, 20), (2.0, 8), (3.0, 20), (2.0, 40), (3.0, 64)])
 def test_knn_graded_cloud_density_levels(ctx, power, k, monkeypatch):
     # coordinates = uniform^p: the density varies by orders of magnitude, so the build adds grids laid
     # out for denser regions and targets whose strip overflows the tile are passed down a level
