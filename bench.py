@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 from multimesh_amd import synth  # noqa: E402
 from multimesh_amd.helpers import STAGES  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a device-to-device copy reaches ~5 TB/s (roofline.measured_copy_GBps)
 
 
 def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
