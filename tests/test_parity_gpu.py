@@ -414,6 +414,28 @@ def test_gll_fused_pipeline_equals_staged_calls_and_oracle(ctx, order, dim):
         assert np.array_equal(v1.numpy()[:, 0], vals_o[:, 1])
 
 
+def test_gll_fused_pipeline_on_a_graded_mesh(ctx):
+    # control nodes warped u -> u^2 per axis: element sizes span two orders of magnitude, the centroid
+    # cloud gets density levels, and the lazily evaluated lists are completed level-aware
+    gp = synth.gll_mesh(17, 2, seed=3, jitter=0.05) ** 2.0                 # 16^3 order-2 elements
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(size=(60_000, 3)) ** 2.0
+    fields = np.stack([synth.field_linear(gp), synth.field_smooth(gp.reshape(-1, 3)).reshape(gp.shape[:2])])
+    nn = O.knn_ckdtree(gp.mean(axis=1), pts, 20, workers=-1)[0]
+    elem_o, co_o, miss_o = O.locate_gll(2, nn, gp, pts, tolerance=1.05, snap_to_nearest=False)
+    vals_o = O.gather_elem(fields, elem_o, co_o)
+    for lazy in (True, False):
+        ctx.set_lazy_lists(lazy)
+        try:
+            vals, elem, co, miss = ctx.interpolate_gll(2, gp, pts, fields, nelem_to_search=20, want_operator=True)
+            v2, miss2 = ctx.interpolate_gll(2, gp, pts, fields, nelem_to_search=20)
+        finally:
+            ctx.set_lazy_lists(True)
+        assert miss == miss_o == miss2
+        assert np.array_equal(elem.numpy(), elem_o) and np.array_equal(co.numpy(), co_o)
+        assert np.array_equal(vals.numpy(), vals_o) and np.array_equal(v2.numpy(), vals_o)
+
+
 def test_gll_api_and_cfg5_shaped_run(ctx):
     # order-4 hexes as in cfg5 (reduced size): targets = the unique GLL points of a second mesh
     from multimesh_amd import api
