@@ -15,15 +15,13 @@ from __future__ import annotations
 
 import ctypes as C
 import glob
-import inspect
 import os
 
 import numpy as np
 
-LIB_DIR = os.path.join(
-    os.path.dirname(os.path.abspath(inspect.getfile(inspect.currentframe()))),
-    "lib",
-)
+#: where the built library lives: <this package>/lib (same place the reference looks, helpers.py:22-27)
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+#: the opened library, kept for the life of the process (the reference keeps its handle the same way)
 cache = []
 
 MM_OK = 0
@@ -55,18 +53,17 @@ def _f64_2d():
 
 
 def load_lib():
-    if cache:  # pragma: no cover
+    if cache:
         return cache[0]
-    # Enable a couple of different library naming schemes (as the reference does).
-    possible_files = sorted(glob.glob(os.path.join(LIB_DIR, "multi_mesh*.so")))
-    if not possible_files:  # pragma: no cover
+    # any file called multi_mesh*.so in lib/ qualifies, the first in sorted order wins (the contract of
+    # the reference loader: same glob, same exception type when nothing is there)
+    candidates = sorted(glob.glob(os.path.join(LIB_DIR, "multi_mesh*.so")))
+    if not candidates:
         raise ValueError(
-            "Could not find suitable MultiMesh shared library "
-            f"(expected {LIB_DIR}/multi_mesh_hip.so; build it with "
-            "`make -C multimesh_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`)."
+            f"no multi_mesh*.so under {LIB_DIR}: build multi_mesh_hip.so with `make -C multimesh_amd/csrc` "
+            "or `python -c 'import __graft_entry__ as g; g.build()'`"
         )
-    filename = possible_files[0]
-    lib = C.CDLL(filename)
+    lib = C.CDLL(candidates[0])
 
     # ---- legacy symbols (reference helpers.py:43-81) ----
     lib.centroid.restype = None
@@ -134,7 +131,7 @@ def load_lib():
     lib.mm_last_timings.restype = C.c_int
     lib.mm_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
 
-    lib._filename = filename
+    lib._filename = candidates[0]
     cache.append(lib)
     return lib
 

@@ -56,6 +56,37 @@ def hex_mesh(n: int, seed: int = 1, jitter: float = 0.2, lo=(0.0, 0.0, 0.0),
     return np.ascontiguousarray(pts), np.ascontiguousarray(conn)
 
 
+def hex_mesh_rows(n: int, start: int, stop: int, seed: int = 1, jitter: float = 0.2):
+    """``hex_mesh(n, seed, jitter)[0][start:stop]`` without building the whole mesh: the rows of
+    a contiguous shard of a big target mesh (cfg4: one rank's 12.6 M of the 465^3 = 100.5 M nodes).
+
+    Only the x-planes the range touches are generated; the jitter stream is positioned with
+    ``bit_generator.advance`` (``Generator.uniform`` draws one 64-bit word per double), so the
+    result is bit-identical to slicing the full mesh (tests/test_synth.py)."""
+    if n < 2 or not 0 <= start <= stop <= n ** 3:
+        raise ValueError("need n >= 2 and 0 <= start <= stop <= n^3")
+    if start == stop:
+        return np.empty((0, 3), dtype=np.float64)
+    plane = n * n
+    i0, i1 = start // plane, (stop - 1) // plane + 1          # x-planes [i0, i1)
+    h = 1.0 / (n - 1)
+    ax = h * np.arange(n, dtype=np.float64)
+    pts = np.empty((i1 - i0, n, n, 3), dtype=np.float64)
+    pts[..., 0] = ax[i0:i1, None, None]
+    pts[..., 1] = ax[None, :, None]
+    pts[..., 2] = ax[None, None, :]
+    if n > 2 and jitter > 0:
+        a, b = max(i0, 1), min(i1, n - 1)                      # interior planes among them
+        if b > a:
+            rng = np.random.default_rng(seed)
+            per_plane = (n - 2) * (n - 2) * 3
+            rng.bit_generator.advance((a - 1) * per_plane)
+            jit = rng.uniform(-jitter, jitter, size=(b - a, n - 2, n - 2, 3)) * h
+            pts[a - i0:b - i0, 1:-1, 1:-1, :] += jit
+    pts = pts.reshape(-1, 3)
+    return np.ascontiguousarray(pts[start - i0 * plane:stop - i0 * plane])
+
+
 def quad_mesh(n: int, seed: int = 1, jitter: float = 0.2):
     """2-D analogue: (points f64[n^2, 2], connectivity int64[(n-1)^2, 4]) counter-clockwise."""
     rng = np.random.default_rng(seed)

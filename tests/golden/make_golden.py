@@ -36,7 +36,11 @@ def run_reference(points_a, conn_exodus, points_b, k, fields):
     """The reference pipeline scripts/cli.py:62-100 on arrays."""
     cen = O.ref_centroid(conn_exodus, points_a)
     nn, dist = O.knn_ckdtree(cen, points_b, k)
-    conn = synth.reorder_hex8(conn_exodus)
+    # the reference's own statement (scripts/cli.py:79-81), written out here so that the A3 fixture does
+    # not depend on this repository's synth.reorder_hex8
+    permutation = [0, 3, 2, 1, 4, 5, 6, 7]
+    i = np.argsort(permutation)
+    conn = np.ascontiguousarray(conn_exodus[:, i])
     enc, w, nfailed = O.ref_locate_hex8(nn, conn, points_a, points_b)
     vals = O.gather_numpy(fields, enc, w)
     return dict(centroid=cen, nn=nn, nn_dist=dist, conn_reordered=conn, enc=enc, w=w,

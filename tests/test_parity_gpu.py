@@ -322,6 +322,93 @@ def test_cfg3_10M_to_10M_vector_field(ctx):
     _full_size_check(ctx, 216, 216, 3, sample=20_000)
 
 
+@pytest.mark.parametrize("shard", [0, 7])
+def test_cfg4_real_shards_of_the_100M_target_mesh(ctx, shard):
+    # cfg4 as the 8-GPU run sees it: rank r's block = shard_bounds(465^3, 8, r) rows of the 465^3 target
+    # mesh -- a 58-plane slab with ~10 targets per source node that touches 1/8 of the 216^3 source
+    # grid (~160 targets per kNN strip: the strips-shared-between-waves regime), NOT a cube of its own.
+    # Shard 0 and shard 7 (the short last one) on the one GPU; properties on all 12.57M targets,
+    # cKDTree + oracle on a 20k sample.
+    from multimesh_amd.distributed import shard_bounds
+
+    n_tgt = synth.CONFIGS["cfg4"]["n_tgt"]
+    lo, hi = shard_bounds(n_tgt ** 3, 8, shard)
+    assert (lo, hi) == ((0, 12_568_079) if shard == 0 else (87_976_553, 100_544_625))
+    pa, ca = synth.hex_mesh(synth.CONFIGS["cfg4"]["n_src"], seed=1)
+    pb = synth.hex_mesh_rows(n_tgt, lo, hi, seed=7)
+    fields = synth.vector_field(pa)[:1]
+    vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+    vals, enc, w = vals.numpy(), enc.numpy(), w.numpy()
+    assert nf == 0
+    assert np.abs(w.sum(axis=1) - 1).max() < 1e-13
+    assert np.abs(vals[:, 0] - synth.field_linear(pb)).max() < 1e-7
+    v2, nf2 = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)      # values only (fused gather)
+    assert nf2 == 0 and np.array_equal(v2.numpy(), vals)
+    pick = np.sort(np.random.default_rng(4 + shard).choice(len(pb), size=20_000, replace=False))
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb[pick], 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb[pick])
+    assert nf_o == 0
+    assert np.array_equal(enc[pick], enc_o) and np.array_equal(w[pick], w_o)
+    assert np.array_equal(vals[pick], O.gather(fields, enc_o, w_o))
+
+
+def test_cfg5_full_size_order4_gll(ctx):
+    # cfg5 at SURVEY section 8's size: 43^3 order-4 source elements (9.94M element-nodal points), targets =
+    # the unique GLL points of the 47^3-element mesh (13.0M element-nodal -> 7.2M unique) through
+    # mm_unique_points + the fused mm_interpolate_gll (reference flow interpolator.py:666-826).
+    # GLL numerics are parity-unpinned (salvus.fem absent): the checks are the analytic properties on
+    # ALL targets and HIP == oracle on a 10k sample.
+    src = synth.gll_mesh(44, 4, seed=1)
+    tgt = synth.gll_mesh(48, 4, seed=7)
+    assert src.shape == (43 ** 3, 125, 3) and tgt.shape == (47 ** 3, 125, 3)
+    uniq, inv = ctx.unique_points(tgt.reshape(-1, 3))
+    U = uniq.shape[0]
+    # 189^3 = 6.75M geometric points; copies of a shared face point computed from different elements
+    # may differ in the last bit and then stay distinct, exactly as for np.unique in the reference
+    assert (47 * 4 + 1) ** 3 <= U < 7_400_000
+    pts = uniq.numpy()
+    assert np.array_equal(pts[inv.numpy()[:100_000]], tgt.reshape(-1, 3)[:100_000])   # the inverse index scatters back
+    fields = np.stack([synth.field_linear(src), np.ones(src.shape[:2])])
+    vals, elem, co, miss = ctx.interpolate_gll(4, src, uniq, fields, nelem_to_search=20, tolerance=1.05,
+                                               want_operator=True)
+    assert miss == 0
+    vals, elem = vals.numpy(), elem.numpy()
+    assert elem.min() >= 0 and elem.max() < src.shape[0]
+    assert np.abs(vals[:, 0] - synth.field_linear(pts)).max() < 1e-11     # linear field reproduced
+    assert np.abs(vals[:, 1] - 1.0).max() < 1e-12                         # sum of coefficients = 1 (constant field)
+    v2, miss2 = ctx.interpolate_gll(4, src, uniq, fields, nelem_to_search=20, tolerance=1.05)   # fused, no operator
+    assert miss2 == 0 and np.array_equal(v2.numpy(), vals)
+    pick = np.sort(np.random.default_rng(5).choice(U, size=10_000, replace=False))
+    co_pick = np.stack([co.rows(int(i), int(i) + 1).numpy()[0] for i in pick[:200]])   # rows of the 6.7 GB operator
+    nn, _ = O.knn_ckdtree(src.mean(axis=1), pts[pick], 20, workers=-1)
+    elem_o, co_o, miss_o = O.locate_gll(4, nn, src, pts[pick], tolerance=1.05, snap_to_nearest=False)
+    assert miss_o == 0
+    assert np.array_equal(elem[pick], elem_o) and np.array_equal(co_pick, co_o[:200])
+    assert np.array_equal(vals[pick], O.gather_elem(fields, elem_o, co_o))
+
+
+@pytest.mark.parametrize("order", [1, 4])
+def test_cfg1_full_size_2d_through_the_api(order):
+    # cfg1 at its own size: 2-D 100x100-node meshes (99^2 quads), GLL -> GLL through the API's array core
+    # (unique targets, locate, gather, scatter back: reference interpolator.py:666-826) against the
+    # oracle on EVERY target
+    from multimesh_amd import api
+
+    src = synth.gll_mesh(100, order, seed=1, dim=2)
+    tgt = synth.gll_mesh(100, order, seed=7, dim=2)
+    f = synth.field_smooth(src.reshape(-1, 2)).reshape(src.shape[:2])
+    mesh = api.GllMesh(src, order, {"f": f, "lin": synth.field_linear(src)})
+    out = api.interpolate_gll_to_gll(mesh, tgt, ["f", "lin"], nelem_to_search=20, tolerance=1.05)
+    assert out.shape == (2,) + tgt.shape[:2]
+    uniq, inv = np.unique(tgt.reshape(-1, 2), axis=0, return_inverse=True)          # reference utils.py:484-488
+    nn, _ = O.knn_ckdtree(src.mean(axis=1), uniq, 20)
+    elem_o, co_o, miss_o = O.locate_gll(order, nn, src, uniq, tolerance=1.05, snap_to_nearest=False)
+    assert miss_o == 0
+    want = O.gather_elem(np.stack([f, synth.field_linear(src)]), elem_o, co_o)[inv.reshape(-1)]
+    assert np.array_equal(out.reshape(2, -1).T, want)
+    assert np.abs(out[1] - synth.field_linear(tgt)).max() < 1e-11
+
+
 def test_graded_meshes_through_the_pipeline(ctx):
     # meshes refined towards a corner (node coordinates u -> u^2.2 per axis: element sizes span three
     # orders of magnitude, so the centroid cloud needs several density levels), source and target of

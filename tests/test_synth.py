@@ -26,3 +26,19 @@ def test_config_sizes_match_survey():
     assert 101 ** 3 == 1030301 and 100 ** 3 == 1000000
     assert 216 ** 3 == 10077696 and 215 ** 3 == 9938375
     assert synth.CONFIGS["metric"]["n_src"] == 216 and synth.CONFIGS["metric"]["ncomp"] == 1
+
+
+def test_hex_mesh_rows_equal_slices_of_the_full_mesh():
+    # cfg4 shards (bench.py --workload cfg4, tests/test_parity_gpu.py) are generated without the 2.4 GB mesh
+    from multimesh_amd.distributed import shard_bounds
+
+    for n, seed in ((2, 3), (3, 7), (9, 7), (12, 11)):
+        full, _ = synth.hex_mesh(n, seed=seed)
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                a, b = shard_bounds(n ** 3, world, r)
+                assert np.array_equal(synth.hex_mesh_rows(n, a, b, seed=seed), full[a:b])
+        for a, b in ((0, 0), (5, 6), (n ** 3 - 1, n ** 3), (n * n - 1, n * n + 1)):
+            if b <= n ** 3:
+                assert np.array_equal(synth.hex_mesh_rows(n, a, b, seed=seed), full[a:b])
+    assert synth.CONFIGS["cfg4"]["n_tgt"] ** 3 == 100_544_625
