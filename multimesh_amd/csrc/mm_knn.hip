@@ -25,6 +25,8 @@
 #include "mm_common.h"
 #include <cstring>
 
+int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -1549,6 +1551,343 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
 #undef MM_NEXT_STRIP
 }
 
+// ---- fast path, 3-D grids, round 2: ONE LANE PER TARGET over an LDS tile ---------------------------
+// The strip kernel above spends three quarters of its instructions outside the distance evaluations:
+// histogram scans, prefix sums inside lane groups, seven hand-over points per round of 8 targets, a
+// dependent global round trip per round.  Here a wave takes 64 targets of a strip of Z cells along z and
+// every lane owns ONE target from start to finish -- no cross-lane step inside a round at all:
+//   tile   : the strip's cells and their neighbours, (Z+2) layers x 9 columns, staged once per work item
+//            as float4 {x, y, z relative to the strip corner, position in the sorted array}, layer-major
+//            (the 27 cells around a target's cell are ONE contiguous window, as in the strip kernel).
+//   scan   : the lane walks its window (same trip count for the whole wave; a shorter window starts
+//            earlier and reads sources of the layer below -- real candidates, just not needed) and keeps
+//            the L = K + 2 smallest KEYS in registers, sorted, by one v_med3_f32 per list slot:
+//            inserting c into an ascending list is  d[s] = med3(d[s-1], c, d[s]).  A key is the fp32
+//            squared distance with its 10 low mantissa bits replaced by the candidate's slot in the
+//            window, so the payload rides along for free: 6 + 1 + L VALU per candidate, no LDS write,
+//            no atomics, no second pass.
+//   exact  : the K + 1 best keys' candidates get the exact fp64 distance in the reference's arithmetic
+//            (coordinates re-read from the fp64 records) and are ranked by (d2, id) in registers.
+//   certify: every candidate outside the list has a key above the list's last one, B.  With the rounding
+//            bound E of the strip kernel (|sqrt(d32) - d| <= E + 2u d) and the 2^-13 the payload can
+//            move a key, such a candidate lies at an exact distance >= LB = (sqrt(B)(1 - 2^-12) - E)(1 - 4u).
+//            The row is accepted only if the exact k-th distance is strictly below LB (and below the
+//            nearest face of the 3x3x3 block, as before); then the list holds every source that can
+//            be among the k nearest, exact ties included.  Otherwise (~never on meshes; near-equal
+//            k-th .. (k+2)-th distances, hull targets) the target goes to the generic kernel.
+// Work items: a prepass turns the strips that hold targets into a list of (strip, part) items of at most
+// kLaneRounds rounds each -- so a slab of densely packed targets over 1/8 of the grid (a cfg4 shard) keeps
+// the whole chip busy --, and XCD x takes the x-th eighth of the list (contiguous in space: its L2 sees
+// each source ~once).
+constexpr int kLaneTileCap = 768;      // sources per tile: (7 + 2) layers x 9 columns x ~8 = 648, + 4.7 sigma (Poisson)
+constexpr int kLaneUnroll = 8;
+constexpr int kLanePad = kLaneUnroll;  // far-away entries behind the tile (a window read may run past it by < kLaneUnroll)
+constexpr int kLaneZ = 7;              // cells per strip: ~57 targets per round of 64 lanes at 8 targets per cell
+constexpr int kLaneZMax = 12;
+constexpr int kLaneRounds = 4;         // rounds (of 64 targets) per work item
+constexpr float kLaneFar = 1e18f;      // sentinel coordinate (squares to 1e36 < FLT_MAX: keys stay finite)
+constexpr float kLaneFarKey = 1e30f;   // keys at or above this are sentinels / absurdly far sources
+
+// per strip: number of work items (0 without targets)
+__global__ __launch_bounds__(kBlock) void lane_items_count_kernel(GridParams g, const int *__restrict__ tstart, int Z,
+                                                                  int per_item, int *__restrict__ nparts, i64 nstrips_total)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nstrips_total) return;
+    const int nstrips = (g.nz + Z - 1) / Z;
+    const int col = (int)(t / nstrips), strip = (int)(t - (i64)col * nstrips);
+    const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
+    const int tn = tstart[col * g.nz + cz1] - tstart[col * g.nz + cz0];
+    nparts[t] = (tn + per_item - 1) / per_item;
+}
+
+__global__ __launch_bounds__(kBlock) void lane_items_fill_kernel(const int *__restrict__ item_start, i64 nstrips_total,
+                                                                 int2 *__restrict__ items)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nstrips_total) return;
+    const int a = item_start[t], b = item_start[t + 1];
+    for (int q = a; q < b; ++q) items[q] = make_int2((int)t, q - a);
+}
+
+// neg_inf: -inf in a register the compiler cannot see through -- med3(-inf, c, d0) = min(c, d0) as ONE
+// v_med3_f32 (a literal -inf is folded into fminf, which costs two canonicalising v_max_f32 more)
+template <int L>
+__device__ __forceinline__ void lane_list_insert(float (&d)[L], float c, float neg_inf)
+{
+#pragma unroll
+    for (int s = L - 1; s >= 1; --s) d[s] = __builtin_amdgcn_fmed3f(d[s - 1], c, d[s]);
+    d[0] = __builtin_amdgcn_fmed3f(neg_inf, c, d[0]);
+}
+
+template <int K, typename IDX>
+__global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 nsrc, const int *__restrict__ cell_start,
+                                                            const double *__restrict__ sorted_xyz, int ndim, int kout,
+                                                            const int *__restrict__ tstart,
+                                                            const double *__restrict__ tsorted, IDX *__restrict__ idx_out,
+                                                            double *__restrict__ dist_out, int *__restrict__ fb_list,
+                                                            int *__restrict__ fb_count, const int2 *__restrict__ items,
+                                                            const int *__restrict__ item_total, int Z, int per_item)
+{
+    constexpr int L = K + 2;        // keys kept per target
+    constexpr int NE = K + 1;       // of which the first K + 1 get exact distances
+    static_assert(K >= 1 && NE <= 32, "rank masks are 32 bits");
+    constexpr double kU = 0x1p-24;
+    __shared__ float4 tile[kLaneTileCap + kLanePad];   // {x, y, z, position in the sorted array (bits)}
+    __shared__ int s_layer[kLaneZMax + 3];
+    __shared__ int s_row[kWave][K | 1];      // output rows in rank order (odd stride: lanes on distinct banks)
+
+    const int lane = threadIdx.x;
+    const int total_items = *item_total;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int first = (int)(((i64)total_items * xcd) >> 3), last = (int)(((i64)total_items * (xcd + 1)) >> 3);
+    const int nstrips = (g.nz + Z - 1) / Z;
+    bool staged_before = false;
+    for (int it = first + (int)(blockIdx.x >> 3); it < last; it += per_xcd) {
+        if (staged_before) wave_sync();   // the previous item's tile and rows are done with
+        staged_before = true;
+        const int2 item = items[it];
+        const int col = item.x / nstrips, strip = item.x - col * nstrips;
+        const int cx = col / g.ny, cy = col - cx * g.ny;
+        const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
+        const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
+        const int nlayers = zb - za + 1;
+        const int ntc = nlayers * 9;                      // <= (kLaneZMax + 2) * 9 = 126 cells: two per lane
+        // ---- extents of the tile's cells (cell q = 9 * layer + column), two per lane
+        int s0[2] = {0, 0}, cnt[2] = {0, 0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int q = lane + 64 * b;
+            const int layer = q / 9, c = q - layer * 9;
+            const int ix = cx + c / 3 - 1, iy = cy + (c - (c / 3) * 3) - 1;
+            if (q < ntc && (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny) {
+                const int cellid = (ix * g.ny + iy) * g.nz + za + layer;
+                s0[b] = cell_start[cellid];
+                cnt[b] = cell_start[cellid + 1] - s0[b];
+            }
+        }
+        int t0 = tstart[col * g.nz + cz0];
+        const int t1 = tstart[col * g.nz + cz1];
+        t0 += item.y * per_item;
+        const int tn = min(per_item, t1 - t0);            // this item's share of the strip's targets
+        const double ox = g.lox + (double)cx * g.hx;
+        const double oy = g.loy + (double)cy * g.hy;
+        const double oz = g.loz + (double)cz0 * g.hz;
+        // ---- tile offsets: prefix sum over the cells in (layer, column) order
+        int off[2], total;
+        {
+            int incl0 = cnt[0], incl1 = cnt[1];
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int a = __shfl_up(incl0, d), b = __shfl_up(incl1, d);
+                if (lane >= d) {
+                    incl0 += a;
+                    incl1 += b;
+                }
+            }
+            const int tot0 = __shfl(incl0, kWave - 1);
+            total = tot0 + __shfl(incl1, kWave - 1);
+            off[0] = incl0 - cnt[0];
+            off[1] = tot0 + incl1 - cnt[1];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int q = lane + 64 * b;
+            if (q < ntc && q % 9 == 0) s_layer[q / 9] = off[b];
+        }
+        if (lane == 0) s_layer[nlayers] = total;
+        if (total > kLaneTileCap) {
+            // too full for the tile (a locally much denser region): the item's targets go to the generic kernel
+            int base = 0;
+            if (lane == 0) base = atomicAdd(fb_count, tn);
+            base = __shfl(base, 0);
+            for (int q = lane; q < tn; q += kWave) fb_list[base + q] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+            continue;
+        }
+        // ---- stage: each lane copies its cells' records, four per trip
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            for (int q = 0; __any(q < cnt[b]); q += 4) {
+                double2 xy[4], zw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const i64 s = (i64)s0[b] + min(q + u, max(cnt[b] - 1, 0));
+                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
+                    xy[u] = r2[0];
+                    zw[u] = r2[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q + u < cnt[b]) {
+                        // non-finite or absurdly far sources become far-away entries (never NaN in a key)
+                        const float fx = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
+                        const float fy = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
+                        const float fz = fminf(fmaxf((float)(zw[u].x - oz), -kLaneFar), kLaneFar);
+                        tile[off[b] + q + u] = make_float4(fx, fy, fz, __int_as_float(s0[b] + q + u));
+                    }
+            }
+        }
+        if (lane < kLanePad) tile[total + lane] = make_float4(kLaneFar, kLaneFar, kLaneFar, __int_as_float(0));
+        wave_sync();   // tile and layer table staged
+
+        // widest window of the strip's cells: the trip count of every lane's scan
+        int maxwin = 0;
+        for (int cz = cz0; cz < cz1; ++cz)
+            maxwin = max(maxwin, s_layer[min(cz + 1, zb) - za + 1] - s_layer[max(cz - 1, za) - za]);
+        const int nsteps = (maxwin + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll;   // < 1024: the payload's 10 bits
+
+        for (int r0 = 0; r0 < tn; r0 += kWave) {
+            const bool valid = r0 + lane < tn;
+            double px, py, pz;
+            i64 i;
+            {
+                const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + r0 + (valid ? lane : 0)) * kRec);
+                const double2 xy = r2[0], zw = r2[1];
+                px = xy.x;
+                py = xy.y;
+                pz = zw.x;
+                i = (i64)record_id(zw.y);
+            }
+            const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
+            const int czl = min(max(cell_coord(pz, g.loz, g.ihz, g.nz), cz0), cz1 - 1);
+            const int l0 = max(czl - 1, za) - za, l1 = min(czl + 1, zb) - za + 1;
+            const int we = s_layer[l1];
+            (void)l0;
+            // every lane reads nsteps entries ending at its window's end (or starting at the tile's start)
+            const int wbase = max(we - nsteps, 0);
+            const float tx = finite ? (float)(px - ox) : 0.f, ty = finite ? (float)(py - oy) : 0.f,
+                        tz = finite ? (float)(pz - oz) : 0.f;
+            float d[L];
+#pragma unroll
+            for (int s = 0; s < L; ++s) d[s] = 3.0e38f;
+            const float4 *wp = tile + wbase;
+            unsigned key_mask = 0xfffffc00u;
+            float neg_inf = -INFINITY;
+            asm volatile("" : "+v"(key_mask), "+v"(neg_inf));   // both stay in registers (see lane_list_insert)
+            for (int j = 0; j < nsteps; j += kLaneUnroll) {
+                float4 q[kLaneUnroll];
+#pragma unroll
+                for (int u = 0; u < kLaneUnroll; ++u) q[u] = wp[j + u];
+#pragma unroll
+                for (int u = 0; u < kLaneUnroll; ++u) {
+                    // the whole entry is asked for: one ds_read_b128 (4 LDS cycles per wave); the 12 bytes alone
+                    // come as a ds_read_b96 (8 cycles), split arrays as ds_read2_b64 + ds_read2_b32 (6 per entry)
+                    asm volatile("" ::"v"(q[u].w));
+                    const float fx = q[u].x - tx, fy = q[u].y - ty, fz = q[u].z - tz;
+                    const float d2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                    // key = (d2 & ~1023) | slot: one v_and_or_b32, the slot (wave-uniform) from a scalar register
+                    float key;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d2), "v"(key_mask), "s"(j + u));
+                    lane_list_insert<L>(d, key, neg_inf);
+                }
+            }
+
+            // ---- exact fp64 distance (reference arithmetic) and source id of the K + 1 best keys
+            double ed[NE];
+            int ei[NE];
+            {
+                int pos[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    pos[e] = __float_as_int(wp[min((int)(__float_as_uint(d[e]) & 1023u), nsteps - 1)].w);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)pos[e] * kRec);
+                    const double2 xy = r2[0], zw = r2[1];
+                    const double dx = xy.x - px;
+                    const double dy = xy.y - py;
+                    const double dz = zw.x - pz;
+                    double d2 = dx * dx;
+                    d2 = d2 + dy * dy;
+                    if (ndim > 2) d2 = d2 + dz * dz;
+                    const bool real = d[e] < kLaneFarKey;
+                    ed[e] = real ? d2 : INFINITY;
+                    ei[e] = real ? record_id(zw.y) : 0x7fffffff - e;   // distinct ids keep sentinels apart
+                }
+            }
+            // rank by exact d2; bit-equal distances (rare) redo the ranks lexicographically by (d2, id)
+            int rank[NE];
+            unsigned seen = 0u;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int rk = 0;
+#pragma unroll
+                for (int f = 0; f < NE; ++f)
+                    if (f != e) rk += ed[f] < ed[e] ? 1 : 0;
+                rank[e] = rk;
+                seen |= 1u << rk;
+            }
+            // distinct distances <=> the ranks are a permutation of 0 .. NE-1 (two sentinels tie as well)
+            if (__any(valid && seen != (NE >= 32 ? ~0u : ((1u << NE) - 1u)))) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    int rk = 0;
+#pragma unroll
+                    for (int f = 0; f < NE; ++f)
+                        if (f != e) rk += before(ed[f], ei[f], ed[e], ei[e]) ? 1 : 0;
+                    rank[e] = rk;
+                }
+            }
+            // the exact k-th distance
+            double kth = INFINITY;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (rank[e] == kout - 1) kth = ed[e];
+            bool hand_over = !finite || !(kth < INFINITY);
+            {
+                // every source outside the list lies at an exact distance >= lb (header comment)
+                const float B = d[L - 1];
+                if (B < kLaneFarKey) {
+                    const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
+                                                 (double)(Z + 1) * g.hz);
+                    const double lb = (sqrt((double)B) * (1.0 - 0x1p-12) - E) * (1.0 - 4.0 * kU);
+                    if (!(lb > 0.0 && kth < lb * lb * (1.0 - 0x1p-40))) hand_over = true;
+                }
+                // could a nearer source sit outside the target's 3x3x3 block?
+                const bool all_x = (cx - 1 <= 0) && (cx + 1 >= g.nx - 1);
+                const bool all_y = (cy - 1 <= 0) && (cy + 1 >= g.ny - 1);
+                const bool all_z = (czl - 1 <= 0) && (czl + 1 >= g.nz - 1);
+                if (!(all_x && all_y && all_z)) {
+                    const double bound = block_bound(g, px, py, pz, cx, cy, czl, 1);
+                    if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
+                }
+            }
+            // rows in rank order through LDS, then wide stores
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (rank[e] < kout) s_row[lane][rank[e]] = ei[e];
+            if (dist_out && valid && !hand_over) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (rank[e] < kout) dist_out[i * kout + rank[e]] = sqrt(ed[e]);
+            }
+            wave_sync();
+            if (valid && !hand_over) {
+                IDX *row = idx_out + i * kout;
+                if (sizeof(IDX) == 4 && (kout & 3) == 0) {
+                    for (int e = 0; e < kout; e += 4)
+                        *reinterpret_cast<int4 *>(row + e) =
+                            make_int4(s_row[lane][e], s_row[lane][e + 1], s_row[lane][e + 2], s_row[lane][e + 3]);
+                } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
+                    for (int e = 0; e < kout; e += 2)
+                        *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_row[lane][e], (i64)s_row[lane][e + 1]);
+                } else {
+                    for (int e = 0; e < kout; ++e) row[e] = (IDX)s_row[lane][e];
+                }
+            }
+            // hand-overs of this round: one atomic per wave
+            const unsigned long long mf = __ballot(valid && hand_over);
+            if (mf) {
+                const int firstl = __ffsll((long long)mf) - 1;
+                int base = 0;
+                if (lane == firstl) base = atomicAdd(fb_count, __popcll(mf));
+                base = __shfl(base, firstl);
+                if (valid && hand_over) fb_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)i;
+            }
+            wave_sync();   // rows are rewritten by the next round
+        }
+    }
+}
+
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
 __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__restrict__ cell_of, i64 npts,
                                                                 const double *__restrict__ pts, int ndim,
@@ -1565,6 +1904,18 @@ __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__re
     store_record(tsorted + pos * kRec, pts[p * ndim], ndim > 1 ? pts[p * ndim + 1] : 0.0,
                  ndim > 2 ? pts[p * ndim + 2] : 0.0, (int)p);
 }
+
+// scratch of the lane kernel's work-item prepass (knn_query_typed carves it)
+constexpr int kLaneMaxK = 20;
+struct LaneWork {
+    int Z;
+    i64 nstrips_total;   // columns x strips per column
+    i64 max_items;       // upper bound on the work items: strips + targets / (64 * kLaneRounds)
+    int *nparts;         // [nstrips_total + 1]
+    int *item_start;     // [nstrips_total + 1]; the last entry is the number of items
+    int *tile_sums;
+    int2 *items;         // [max_items]
+};
 
 template <int K, typename IDX>
 void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
@@ -1612,7 +1963,7 @@ template <int K, typename IDX>
 void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
                  int kout, const int *tstart, const double *tsorted, IDX *idx, double *dist,
                  int *fb_list, int *fb_count, int *down_list, int *down_count, bool record_stage,
-                 unsigned *strip_list, int *strip_count)
+                 unsigned *strip_list, int *strip_count, const LaneWork *lane)
 {
 #ifndef MM_KNN_CAP_EXTRA_SMALL   // tuning builds only
 #define MM_KNN_CAP_EXTRA_SMALL 8
@@ -1626,6 +1977,27 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
     // strips along z need a grid that is deep in z; flat and 2-D grids keep the cell kernel
     static const int force = getenv("MM_KNN_KERNEL") ? (strcmp(getenv("MM_KNN_KERNEL"), "strip") == 0 ? 1 : 2) : 0;
     const bool use_strip = force == 1 || (force == 0 && ix->dims[2] >= 6);
+    if (lane && K <= kLaneMaxK) {
+        // round 2's kernel: work items from the strips that hold targets, then one lane per target
+        constexpr int KL = K <= kLaneMaxK ? K : 1;   // (the strip-only list lengths are never instantiated)
+        const int per_item = kWave * kLaneRounds;
+        const unsigned gs = (unsigned)((lane->nstrips_total + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(lane_items_count_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, g, tstart, lane->Z, per_item,
+                           lane->nparts, lane->nstrips_total);
+        (void)mm_exclusive_scan_int(ctx, lane->nparts, lane->nstrips_total, lane->item_start, lane->tile_sums);
+        hipLaunchKernelGGL(lane_items_fill_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, lane->item_start,
+                           lane->nstrips_total, lane->items);
+        static const i64 force_grid = getenv("MM_KNN_LANE_GRID") ? atoll(getenv("MM_KNN_LANE_GRID")) : 0;
+        i64 wgs = force_grid > 0 ? force_grid : lane->max_items;
+        wgs = (wgs + 7) / 8 * 8;
+        if (wgs > ((i64)1 << 22)) wgs = (i64)1 << 22;
+        if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
+        hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
+                           ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count,
+                           lane->items, lane->item_start + lane->nstrips_total, lane->Z, per_item);
+        if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
+        return;
+    }
     if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
     if (use_strip) {
         const i64 nstrips = (ix->dims[2] + kStripZ - 1) / kStripZ;
@@ -1968,6 +2340,24 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         ++nlevels;
     }
     need += mm_round256((size_t)npts * sizeof(int)) + 256;           // stragglers of all levels (one list)
+    // One lane per target (knn_lane_kernel) when there is a single grid that is deep in z, the lists are
+    // short and there are enough targets per cell to fill 64-lane rounds; otherwise the strip / cell kernels.
+    // MM_KNN_KERNEL=lane|strip|cell forces a kernel (tuning and tests only).
+    static const char *force_kernel = getenv("MM_KNN_KERNEL");
+    LaneWork lane_work;
+    bool use_lane = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK && npts >= 2 * ix->ncells;
+    if (force_kernel) use_lane = strcmp(force_kernel, "lane") == 0 && !ix->fine && ix->dims[2] >= 2 && k <= kLaneMaxK;
+    if (use_lane) {
+        static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
+        lane_work.Z = force_z >= 1 && force_z <= kLaneZMax ? force_z : kLaneZ;
+        if (lane_work.Z > ix->dims[2]) lane_work.Z = ix->dims[2];
+        const i64 nstrips = (ix->dims[2] + lane_work.Z - 1) / lane_work.Z;
+        lane_work.nstrips_total = (i64)ix->dims[0] * ix->dims[1] * nstrips;
+        lane_work.max_items = lane_work.nstrips_total + npts / (kWave * kLaneRounds) + 8;
+        need += 2 * mm_round256((size_t)(lane_work.nstrips_total + 1) * sizeof(int)) +
+                mm_round256((size_t)((lane_work.nstrips_total + kScanTile) / kScanTile) * sizeof(int)) +
+                mm_round256((size_t)lane_work.max_items * sizeof(int2)) + 1024;
+    }
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) return rc;
     int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
@@ -1975,6 +2365,16 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     if (!fb_list || !fb_count) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
+    }
+    if (use_lane) {
+        lane_work.nparts = (int *)mm_scratch_take(ctx, (size_t)(lane_work.nstrips_total + 1) * sizeof(int));
+        lane_work.item_start = (int *)mm_scratch_take(ctx, (size_t)(lane_work.nstrips_total + 1) * sizeof(int));
+        lane_work.tile_sums = (int *)mm_scratch_take(ctx, (size_t)((lane_work.nstrips_total + kScanTile) / kScanTile) * sizeof(int));
+        lane_work.items = (int2 *)mm_scratch_take(ctx, (size_t)lane_work.max_items * sizeof(int2));
+        if (!lane_work.nparts || !lane_work.item_start || !lane_work.tile_sums || !lane_work.items) {
+            mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+            return MM_ERR_ALLOC;
+        }
     }
     MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
@@ -2009,7 +2409,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                            start, tsorted, list, list_count);
 #define MM_FAST(KK)                                                                                                  \
     launch_fast<KK, IDX>(ctx, l, gl, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count, down_list, \
-                         down_count, level == 0, strip_list, strip_count)
+                         down_count, level == 0, strip_list, strip_count, use_lane ? &lane_work : nullptr)
         if (k <= 1) MM_FAST(1);
         else if (k <= 2) MM_FAST(2);
         else if (k <= 4) MM_FAST(4);

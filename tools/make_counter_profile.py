@@ -1,0 +1,70 @@
+"""Per-kernel means of the rocprofv3 counter passes collected by tools/knn_counters.sh.
+
+usage: make_counter_profile.py <dir with pass*/ csv trees> <out.json>
+Every counter is summed over a dispatch's rows (rocprofv3 writes one row per dispatch, counter and
+dimension instance) and averaged over the dispatches of a kernel; kernel durations come from the kernel
+trace of the same passes.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
+(MI355X_MICROARCH.md, cycle-constants table).  Derived: instructions per wave, busy shares of the
+wave-cycles, L2 hit rate.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+PATTERNS = {"knn_strip_kernel": "knn_strip_kernel", "knn_lane_kernel": "knn_lane_kernel",
+            "locate_pass_kernel": "locate_pass_kernel", "centroid_bbox_kernel": "centroid_bbox",
+            "gather8_kernel": "gather8_kernel", "cell_scatter_kernel": "cell_scatter", "target_scatter_kernel": "target_scatter",
+            "cell_count_kernel": "cell_count"}
+
+
+def short(name):
+    for k, pat in PATTERNS.items():
+        if pat in name:
+            return k
+    return None
+
+
+sums = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+for f in glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k:
+            sums[k][r["Counter_Name"]][(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
+dur = collections.defaultdict(list)
+for f in glob.glob(root + "/pass*/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k:
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+
+res = {"_note": " ".join(__doc__.split("\n\n", 1)[1].split())}
+for k, counters in sorted(sums.items()):
+    # the largest dispatches only (the locate pass kernel is launched again on small remainders)
+    e = {}
+    for c, per in counters.items():
+        vals = sorted(per.values(), reverse=True)
+        top = [v for v in vals if v >= 0.5 * vals[0]] if vals[0] > 0 else vals
+        e[c] = round(sum(top) / len(top), 1)
+    if dur[k]:
+        d = sorted(dur[k], reverse=True)
+        top = [v for v in d if v >= 0.5 * d[0]]
+        e["duration_ms_under_profiler"] = round(sum(top) / len(top), 4)
+    w = e.get("SQ_WAVES")
+    if w:
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
+            if c in e:
+                e[c + "_per_wave"] = round(e[c] / w, 1)
+    wc = e.get("SQ_WAVE_CYCLES")
+    if wc:
+        for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+                  "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if c in e:
+                e[c + "_share_of_wave_cycles"] = round(e[c] / wc, 4)
+    if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
+        e["L2_hit_rate"] = round(e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"]), 4)
+    res[k] = e
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k in ("knn_strip_kernel", "knn_lane_kernel")}, indent=1))
