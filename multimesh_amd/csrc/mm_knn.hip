@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
 // each source ~once).
 constexpr int kLaneTileCap = 768;      // sources per tile: (7 + 2) layers x 9 columns x ~8 = 648, + 4.7 sigma (Poisson)
 constexpr int kLaneUnroll = 8;
-constexpr int kLanePad = kLaneUnroll;  // far-away entries behind the tile (a window read may run past it by < kLaneUnroll)
+constexpr int kLanePad = 16;           // far-away entries behind the tile (a window read may run past it by < 12 entries)
 constexpr int kLaneZ = 7;              // cells per strip: ~57 targets per round of 64 lanes at 8 targets per cell
 constexpr int kLaneZMax = 12;
 constexpr int kLaneRounds = 4;         // rounds (of 64 targets) per work item
@@ -1632,16 +1632,18 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
     constexpr int L = K + 2;        // keys kept per target
     constexpr int NE = K + 1;       // of which the first K + 1 get exact distances
     static_assert(K >= 1 && NE <= 32, "rank masks are 32 bits");
+    constexpr bool kRowsInLds = K > 8;   // short rows are put in rank order in registers (no LDS: one more wave per SIMD)
     constexpr double kU = 0x1p-24;
-    __shared__ float4 tile[kLaneTileCap + kLanePad];   // {x, y, z, position in the sorted array (bits)}
+    __shared__ float4 tile[kLaneTileCap + kLanePad];   // {x, y, z, position in the sorted array (bits; -1: padding)}
     __shared__ int s_layer[kLaneZMax + 3];
-    __shared__ int s_row[kWave][K | 1];      // output rows in rank order (odd stride: lanes on distinct banks)
+    __shared__ int s_row[kRowsInLds ? kWave : 1][K | 1];   // long rows in rank order (odd stride: lanes on distinct banks)
 
     const int lane = threadIdx.x;
     const int total_items = *item_total;
     const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
     const int first = (int)(((i64)total_items * xcd) >> 3), last = (int)(((i64)total_items * (xcd + 1)) >> 3);
     const int nstrips = (g.nz + Z - 1) / Z;
+    const float4 far_entry = make_float4(kLaneFar, kLaneFar, kLaneFar, __int_as_float(-1));
     bool staged_before = false;
     for (int it = first + (int)(blockIdx.x >> 3); it < last; it += per_xcd) {
         if (staged_before) wave_sync();   // the previous item's tile and rows are done with
@@ -1673,7 +1675,17 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         const double ox = g.lox + (double)cx * g.hx;
         const double oy = g.loy + (double)cy * g.hy;
         const double oz = g.loz + (double)cz0 * g.hz;
-        // ---- tile offsets: prefix sum over the cells in (layer, column) order
+        // the first round's targets: in flight while the tile is staged
+        double npx, npy, npz, npw;
+        {
+            const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (lane < tn ? lane : 0)) * kRec);
+            const double2 xy = r2[0], zw = r2[1];
+            npx = xy.x;
+            npy = xy.y;
+            npz = zw.x;
+            npw = zw.y;
+        }
+        // ---- tile offsets: prefix sum over the cells in (layer, column) order ...
         int off[2], total;
         {
             int incl0 = cnt[0], incl1 = cnt[1];
@@ -1684,17 +1696,40 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                     incl1 += b;
                 }
             }
-            const int tot0 = __shfl(incl0, kWave - 1);
-            total = tot0 + __shfl(incl1, kWave - 1);
-            off[0] = incl0 - cnt[0];
-            off[1] = tot0 + incl1 - cnt[1];
+            const int tot0 = __builtin_amdgcn_readlane(incl0, kWave - 1);
+            const int nat_total = tot0 + __builtin_amdgcn_readlane(incl1, kWave - 1);
+            const int nat0 = incl0 - cnt[0], nat1 = tot0 + incl1 - cnt[1];   // offsets without padding
+            // ... with every layer's start moved up (by at most 3 far-away entries) so that it differs mod 16
+            // from the three layer starts before it.  A lane's scan reads entry (its window's end - nsteps + j)
+            // at step j, the window ends are layer starts, a ds_read_b128 serves 16 lanes (targets of ~4
+            // consecutive cells) per LDS cycle, and entries that are equal mod 16 share their four banks:
+            // with the natural layer size (~72 = 8 mod 16) every second layer collides (measured: 55 % of
+            // the LDS cycles were bank-conflict cycles).
+            int start = 0, shift0 = 0, shift1 = 0, r1 = -1, r2 = -1, r3 = -1, nat_prev = 0;
+            const int layer0 = lane / 9, layer1 = (lane + 64) / 9;
+            for (int Ly = 0; Ly <= nlayers; ++Ly) {
+                const int q = 9 * Ly;
+                const int nat = Ly == nlayers ? nat_total
+                                              : (q < kWave ? __builtin_amdgcn_readlane(nat0, q) : __builtin_amdgcn_readlane(nat1, q - kWave));
+                start += nat - nat_prev;
+                nat_prev = nat;
+                if (Ly > 0 && Ly < nlayers) {
+                    for (int bump = 0; bump < 3 && ((start & 15) == r1 || (start & 15) == r2 || (start & 15) == r3); ++bump) {
+                        if (lane == 0 && start < kLaneTileCap) tile[start] = far_entry;
+                        ++start;
+                    }
+                }
+                r3 = r2;
+                r2 = r1;
+                r1 = start & 15;
+                if (lane == 0) s_layer[Ly] = start;
+                if (Ly == layer0) shift0 = start - nat;
+                if (Ly == layer1) shift1 = start - nat;
+            }
+            total = start;
+            off[0] = nat0 + shift0;
+            off[1] = nat1 + shift1;
         }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int q = lane + 64 * b;
-            if (q < ntc && q % 9 == 0) s_layer[q / 9] = off[b];
-        }
-        if (lane == 0) s_layer[nlayers] = total;
         if (total > kLaneTileCap) {
             // too full for the tile (a locally much denser region): the item's targets go to the generic kernel
             int base = 0;
@@ -1703,30 +1738,40 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             for (int q = lane; q < tn; q += kWave) fb_list[base + q] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
             continue;
         }
-        // ---- stage: each lane copies its cells' records, four per trip
+        // ---- stage, step 1: every entry's position in the sorted array (the cells' owners know them) ...
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            for (int q = 0; __any(q < cnt[b]); q += 4) {
-                double2 xy[4], zw[4];
+        for (int b = 0; b < 2; ++b)
+            for (int q = 0; q < cnt[b]; ++q) reinterpret_cast<int *>(tile + off[b] + q)[3] = s0[b] + q;
+        if (lane < kLanePad) tile[total + lane] = far_entry;   // a window read may run past the tile's end
+        wave_sync();
+        // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, four records in flight per
+        // lane, ONE global round trip for the whole tile (copying cell by cell was a chain of them)
+        for (int e0 = 0; e0 < total; e0 += 4 * kWave) {
+            int pos[4];
+            double2 xy[4], zw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const i64 s = (i64)s0[b] + min(q + u, max(cnt[b] - 1, 0));
-                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + s * kRec);
-                    xy[u] = r2[0];
-                    zw[u] = r2[1];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (q + u < cnt[b]) {
-                        // non-finite or absurdly far sources become far-away entries (never NaN in a key)
-                        const float fx = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
-                        const float fy = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
-                        const float fz = fminf(fmaxf((float)(zw[u].x - oz), -kLaneFar), kLaneFar);
-                        tile[off[b] + q + u] = make_float4(fx, fy, fz, __int_as_float(s0[b] + q + u));
-                    }
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * kWave + lane;
+                pos[u] = e < total ? reinterpret_cast<const int *>(tile + e)[3] : -1;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)max(pos[u], 0) * kRec);
+                xy[u] = r2[0];
+                zw[u] = r2[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pos[u] >= 0) {
+                    // non-finite or absurdly far sources become far-away entries (never NaN in a key)
+                    const float fx = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
+                    const float fy = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
+                    const float fz = fminf(fmaxf((float)(zw[u].x - oz), -kLaneFar), kLaneFar);
+                    float *dst = reinterpret_cast<float *>(tile + e0 + u * kWave + lane);
+                    *reinterpret_cast<float2 *>(dst) = make_float2(fx, fy);
+                    dst[2] = fz;
+                }
         }
-        if (lane < kLanePad) tile[total + lane] = make_float4(kLaneFar, kLaneFar, kLaneFar, __int_as_float(0));
         wave_sync();   // tile and layer table staged
 
         // widest window of the strip's cells: the trip count of every lane's scan
@@ -1737,21 +1782,21 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 
         for (int r0 = 0; r0 < tn; r0 += kWave) {
             const bool valid = r0 + lane < tn;
-            double px, py, pz;
-            i64 i;
-            {
-                const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + r0 + (valid ? lane : 0)) * kRec);
+            const double px = npx, py = npy, pz = npz;
+            const i64 i = (i64)record_id(npw);
+            if (r0 + kWave < tn) {
+                // the next round's targets, in flight during this round
+                const int q = r0 + kWave + lane;
+                const double2 *r2 = reinterpret_cast<const double2 *>(tsorted + (i64)(t0 + (q < tn ? q : 0)) * kRec);
                 const double2 xy = r2[0], zw = r2[1];
-                px = xy.x;
-                py = xy.y;
-                pz = zw.x;
-                i = (i64)record_id(zw.y);
+                npx = xy.x;
+                npy = xy.y;
+                npz = zw.x;
+                npw = zw.y;
             }
             const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
             const int czl = min(max(cell_coord(pz, g.loz, g.ihz, g.nz), cz0), cz1 - 1);
-            const int l0 = max(czl - 1, za) - za, l1 = min(czl + 1, zb) - za + 1;
-            const int we = s_layer[l1];
-            (void)l0;
+            const int we = s_layer[min(czl + 1, zb) - za + 1];
             // every lane reads nsteps entries ending at its window's end (or starting at the tile's start)
             const int wbase = max(we - nsteps, 0);
             const float tx = finite ? (float)(px - ox) : 0.f, ty = finite ? (float)(py - oy) : 0.f,
@@ -1763,20 +1808,35 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             unsigned key_mask = 0xfffffc00u;
             float neg_inf = -INFINITY;
             asm volatile("" : "+v"(key_mask), "+v"(neg_inf));   // both stay in registers (see lane_list_insert)
+            // two half-chunks in flight: the LDS reads of one are issued before the other is consumed
+            constexpr int H = kLaneUnroll / 2;
+            float4 qa[H], qb[H];
+#pragma unroll
+            for (int u = 0; u < H; ++u) qa[u] = wp[u];
             for (int j = 0; j < nsteps; j += kLaneUnroll) {
-                float4 q[kLaneUnroll];
 #pragma unroll
-                for (int u = 0; u < kLaneUnroll; ++u) q[u] = wp[j + u];
+                for (int u = 0; u < H; ++u) qb[u] = wp[j + H + u];
 #pragma unroll
-                for (int u = 0; u < kLaneUnroll; ++u) {
+                for (int u = 0; u < H; ++u) {
                     // the whole entry is asked for: one ds_read_b128 (4 LDS cycles per wave); the 12 bytes alone
                     // come as a ds_read_b96 (8 cycles), split arrays as ds_read2_b64 + ds_read2_b32 (6 per entry)
-                    asm volatile("" ::"v"(q[u].w));
-                    const float fx = q[u].x - tx, fy = q[u].y - ty, fz = q[u].z - tz;
+                    asm volatile("" ::"v"(qa[u].w));
+                    const float fx = qa[u].x - tx, fy = qa[u].y - ty, fz = qa[u].z - tz;
                     const float d2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
                     // key = (d2 & ~1023) | slot: one v_and_or_b32, the slot (wave-uniform) from a scalar register
                     float key;
                     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d2), "v"(key_mask), "s"(j + u));
+                    lane_list_insert<L>(d, key, neg_inf);
+                }
+#pragma unroll
+                for (int u = 0; u < H; ++u) qa[u] = wp[j + kLaneUnroll + u];   // (past the last chunk: the padding)
+#pragma unroll
+                for (int u = 0; u < H; ++u) {
+                    asm volatile("" ::"v"(qb[u].w));
+                    const float fx = qb[u].x - tx, fy = qb[u].y - ty, fz = qb[u].z - tz;
+                    const float d2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                    float key;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d2), "v"(key_mask), "s"(j + H + u));
                     lane_list_insert<L>(d, key, neg_inf);
                 }
             }
@@ -1791,7 +1851,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                     pos[e] = __float_as_int(wp[min((int)(__float_as_uint(d[e]) & 1023u), nsteps - 1)].w);
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)pos[e] * kRec);
+                    const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)max(pos[e], 0) * kRec);
                     const double2 xy = r2[0], zw = r2[1];
                     const double dx = xy.x - px;
                     const double dy = xy.y - py;
@@ -1851,27 +1911,55 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                     if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
                 }
             }
-            // rows in rank order through LDS, then wide stores
-#pragma unroll
-            for (int e = 0; e < NE; ++e)
-                if (rank[e] < kout) s_row[lane][rank[e]] = ei[e];
             if (dist_out && valid && !hand_over) {
 #pragma unroll
                 for (int e = 0; e < NE; ++e)
                     if (rank[e] < kout) dist_out[i * kout + rank[e]] = sqrt(ed[e]);
             }
-            wave_sync();
-            if (valid && !hand_over) {
-                IDX *row = idx_out + i * kout;
-                if (sizeof(IDX) == 4 && (kout & 3) == 0) {
-                    for (int e = 0; e < kout; e += 4)
-                        *reinterpret_cast<int4 *>(row + e) =
-                            make_int4(s_row[lane][e], s_row[lane][e + 1], s_row[lane][e + 2], s_row[lane][e + 3]);
-                } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
-                    for (int e = 0; e < kout; e += 2)
-                        *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_row[lane][e], (i64)s_row[lane][e + 1]);
-                } else {
-                    for (int e = 0; e < kout; ++e) row[e] = (IDX)s_row[lane][e];
+            if (kRowsInLds) {
+                // rows in rank order through LDS, then wide stores
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (rank[e] < kout) s_row[lane][rank[e]] = ei[e];
+                wave_sync();
+                if (valid && !hand_over) {
+                    IDX *row = idx_out + i * kout;
+                    if (sizeof(IDX) == 4 && (kout & 3) == 0) {
+                        for (int e = 0; e < kout; e += 4)
+                            *reinterpret_cast<int4 *>(row + e) =
+                                make_int4(s_row[lane][e], s_row[lane][e + 1], s_row[lane][e + 2], s_row[lane][e + 3]);
+                    } else if (sizeof(IDX) == 8 && (kout & 1) == 0) {
+                        for (int e = 0; e < kout; e += 2)
+                            *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)s_row[lane][e], (i64)s_row[lane][e + 1]);
+                    } else {
+                        for (int e = 0; e < kout; ++e) row[e] = (IDX)s_row[lane][e];
+                    }
+                }
+            } else {
+                // short rows: the id of rank r is picked out of the K + 1 entries in registers
+                int out[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    int v = 0;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) v = rank[e] == r ? ei[e] : v;
+                    out[r] = v;
+                }
+                if (valid && !hand_over) {
+                    IDX *row = idx_out + i * kout;
+                    if (sizeof(IDX) == 4 && K % 4 == 0 && kout == K) {
+#pragma unroll
+                        for (int e = 0; e < K; e += 4)
+                            *reinterpret_cast<int4 *>(row + e) = make_int4(out[e], out[e + 1], out[e + 2], out[e + 3]);
+                    } else if (sizeof(IDX) == 8 && K % 2 == 0 && kout == K) {
+#pragma unroll
+                        for (int e = 0; e < K; e += 2)
+                            *reinterpret_cast<longlong2 *>(row + e) = make_longlong2((i64)out[e], (i64)out[e + 1]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < K; ++e)
+                            if (e < kout) row[e] = (IDX)out[e];
+                    }
                 }
             }
             // hand-overs of this round: one atomic per wave
@@ -1883,7 +1971,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 base = __shfl(base, firstl);
                 if (valid && hand_over) fb_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)i;
             }
-            wave_sync();   // rows are rewritten by the next round
+            if (kRowsInLds) wave_sync();   // rows are rewritten by the next round
         }
     }
 }
