@@ -1588,6 +1588,24 @@ constexpr int kLaneRounds = 4;         // rounds (of 64 targets) per work item
 constexpr float kLaneFar = 1e18f;      // sentinel coordinate (squares to 1e36 < FLT_MAX: keys stay finite)
 constexpr float kLaneFarKey = 1e30f;   // keys at or above this are sentinels / absurdly far sources
 
+
+// Diagnostic builds only (make EXTRA=-DMM_LANE_STAMPS): where a wave of knn_lane_kernel spends its cycles.
+// Phase sums (s_memtime ticks = shader cycles) per workgroup slot; tools/lane_stamps.py prints the shares.
+#ifdef MM_LANE_STAMPS
+constexpr int kStampSlots = 1 << 18;
+__device__ unsigned long long g_lane_stamps[kStampSlots * 8];   // per workgroup: 7 phase sums + a wave count
+#define MM_STAMP(n)                                                                    \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
+        stamp_sum[n] += now_ - stamp_last;                                             \
+        stamp_last = now_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#else
+#define MM_STAMP(n) do { } while (0)
+#endif
 // per strip: number of work items (0 without targets)
 __global__ __launch_bounds__(kBlock) void lane_items_count_kernel(GridParams g, const int *__restrict__ tstart, int Z,
                                                                   int per_item, int *__restrict__ nparts, i64 nstrips_total)
@@ -1639,6 +1657,11 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
     __shared__ int s_row[kRowsInLds ? kWave : 1][K | 1];   // long rows in rank order (odd stride: lanes on distinct banks)
 
     const int lane = threadIdx.x;
+#ifdef MM_LANE_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const int total_items = *item_total;
     const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
     const int first = (int)(((i64)total_items * xcd) >> 3), last = (int)(((i64)total_items * (xcd + 1)) >> 3);
@@ -1649,6 +1672,10 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         if (staged_before) wave_sync();   // the previous item's tile and rows are done with
         staged_before = true;
         const int2 item = items[it];
+#ifdef MM_LANE_STAMPS
+        asm volatile("" ::"s"(item.x));
+#endif
+        MM_STAMP(0);   // kernel start / previous item -> item descriptor here
         const int col = item.x / nstrips, strip = item.x - col * nstrips;
         const int cx = col / g.ny, cy = col - cx * g.ny;
         const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
@@ -1730,6 +1757,10 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             off[0] = nat0 + shift0;
             off[1] = nat1 + shift1;
         }
+#ifdef MM_LANE_STAMPS
+        asm volatile("" ::"v"(off[0]), "v"(off[1]));
+#endif
+        MM_STAMP(1);   // cell extents arrived, offsets computed
         if (total > kLaneTileCap) {
             // too full for the tile (a locally much denser region): the item's targets go to the generic kernel
             int base = 0;
@@ -1744,6 +1775,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             for (int q = 0; q < cnt[b]; ++q) reinterpret_cast<int *>(tile + off[b] + q)[3] = s0[b] + q;
         if (lane < kLanePad) tile[total + lane] = far_entry;   // a window read may run past the tile's end
         wave_sync();
+        MM_STAMP(2);   // positions written
         // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, four records in flight per
         // lane, ONE global round trip for the whole tile (copying cell by cell was a chain of them)
         for (int e0 = 0; e0 < total; e0 += 4 * kWave) {
@@ -1773,6 +1805,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 }
         }
         wave_sync();   // tile and layer table staged
+        MM_STAMP(3);   // records gathered, converted, in LDS
 
         // widest window of the strip's cells: the trip count of every lane's scan
         int maxwin = 0;
@@ -1841,6 +1874,10 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 }
             }
 
+#ifdef MM_LANE_STAMPS
+            asm volatile("" ::"v"(d[0]), "v"(d[L - 1]));
+#endif
+            MM_STAMP(4);   // scan
             // ---- exact fp64 distance (reference arithmetic) and source id of the K + 1 best keys
             double ed[NE];
             int ei[NE];
@@ -1864,6 +1901,10 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                     ei[e] = real ? record_id(zw.y) : 0x7fffffff - e;   // distinct ids keep sentinels apart
                 }
             }
+#ifdef MM_LANE_STAMPS
+            asm volatile("" ::"v"(ed[0]), "v"(ed[NE - 1]));
+#endif
+            MM_STAMP(5);   // exact distances here
             // rank by exact d2; bit-equal distances (rare) redo the ranks lexicographically by (d2, id)
             int rank[NE];
             unsigned seen = 0u;
@@ -1972,8 +2013,16 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 if (valid && hand_over) fb_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)i;
             }
             if (kRowsInLds) wave_sync();   // rows are rewritten by the next round
+            MM_STAMP(6);   // ranks, certification, output
         }
     }
+#ifdef MM_LANE_STAMPS
+    if (lane == 0) {
+        unsigned long long *slot = g_lane_stamps + (size_t)(blockIdx.x & (kStampSlots - 1)) * 8;
+        for (int q = 0; q < 7; ++q) slot[q] += stamp_sum[q];   // (grids beyond the slot count alias: sums only)
+        slot[7] += 1ull;
+    }
+#endif
 }
 
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
@@ -2624,6 +2673,26 @@ extern "C" int mm_knn_query(mm_context *ctx, const mm_knn_index *index, const do
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     return rc;
 }
+
+#ifdef MM_LANE_STAMPS
+extern "C" int mm_debug_lane_stamps(unsigned long long *out16, int reset)
+{
+    static unsigned long long *host = nullptr;
+    const size_t bytes = (size_t)kStampSlots * 8 * sizeof(unsigned long long);
+    if (!host) host = (unsigned long long *)calloc(1, bytes);
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lane_stamps), bytes) != hipSuccess) return -1;
+    for (int q = 0; q < 16; ++q) out16[q] = 0;
+    for (size_t b = 0; b < (size_t)kStampSlots; ++b) {
+        for (int q = 0; q < 7; ++q) out16[q] += host[b * 8 + q];
+        out16[15] += host[b * 8 + 7];
+    }
+    if (reset) {
+        memset(host, 0, bytes);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stamps), host, bytes) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" void mm_knn_destroy(mm_context *ctx, mm_knn_index *index)
 {
