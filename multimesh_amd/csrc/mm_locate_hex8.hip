@@ -312,26 +312,45 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
 }
 
 #ifndef MM_PASS_ITERS   // tuning builds only
-#define MM_PASS_ITERS 10
+#define MM_PASS_ITERS 6
 #endif
-constexpr int kPassIters = MM_PASS_ITERS;
+#ifndef MM_MID_ITERS
+#define MM_MID_ITERS 9
+#endif
+// Newton caps of the three tiers of solves (loop trips; a solve that converges after n updates needs
+// n + 1 trips, the last one only evaluates the residual).  Measured on the metric meshes with the
+// reference's arithmetic: 99.99 % of the ACCEPTED solves take 3 or 4 updates, rejected candidates
+// mostly 4, 1.6 % five, 0.3 % six to thirteen, and 0.6 % never converge (the reference gives those
+// its full 50).  A wave runs in lock step, so every round costs the trips of its slowest lane:
+// with one cap of 10 for everybody 42 % of the rounds ran to 10 for the sake of one lane (6.5 trips
+// per round on average against 5 for the mean solve).
+constexpr int kPassIters = MM_PASS_ITERS;   // ordinary solves: fresh targets and retries
+constexpr int kMidIters = MM_MID_ITERS;     // solves that outlast kPassIters, in each other's company
+constexpr int kRefIters = 50;               // the reference's own cap (trilinearinterpolator.c:264)
 
 
-// One compacting pass (see "Scheduling" in the header comment).  q_in == null: the open set is
-// every target, starting at candidate 0.
+// One pass over all targets (see "Scheduling" in the header comment).
 //
-// Persistent waves with a private retry queue.  Re-queueing every unresolved target through a global
+// Persistent waves with private queues.  Re-queueing every unresolved target through a global
 // queue costs twice: a single device-scope counter serves only ~88 returning atomics per microsecond
 // (MI355X_MICROARCH.md, "dequeue"), and -- measured with TCC_MISS -- a later pass over the sparse
 // survivors (a third of the targets after the first solve) misses ~7.6 cache lines per solve against
 // 4.2 in the first pass, because it touches nearly every line of the candidate rows, points and
 // mesh again for a fraction of the work.  So a wave keeps its unresolved targets in LDS and retries
 // them itself as soon as it has a full wave of them, and drains the remainder with a few partly
-// filled rounds once its input is exhausted.  Only targets whose current candidate needs more than
-// kPassIters Newton iterations leave the wave: they are parked in a global "long" queue (about 1 %
-// of the targets) for a second launch of the same kernel with the reference's cap of 50.
+// filled rounds once its input is exhausted.  A solve that outlasts its cap is not abandoned to
+// another launch either (three nearly empty persistent launches used to cost 0.3 ms): the target
+// waits, same candidate, in the wave's queue of the next tier -- kPassIters -> kMidIters -> the
+// reference's 50 -- and is solved again from xi = 0 (the iteration is deterministic: same iterates,
+// same verdict) in a round where slow solves only keep each other company.  "Not converged" under
+// the reference's cap rejects the candidate, as in the reference.
 constexpr int kPassBlock = 256;
-constexpr int kWaveQueue = 128;   // LDS entries per wave (see the append below)
+// LDS entries per wave and queue.  A full queue (>= 64 waiting) is served before anything is added to it, the
+// slowest tier first: tiers 1 and 2 only grow in rounds of the tier below, which run while they hold fewer
+// than 64 (< 128 after the round); tier 0 grows in every round -- 63 + 64 from its own rounds, then one
+// round each of tiers 1 and 2 before it is served again: < 256.
+constexpr int kWaveQueue0 = 256;
+constexpr int kWaveQueue = 128;
 
 // LDS accesses of one wave are served in program order; only the compiler has to be kept from
 // moving them across the hand-over points of the wave's queue.
@@ -343,80 +362,98 @@ __device__ __forceinline__ void wave_fence()
 }
 
 template <bool EXODUS, typename IDX>
-__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, i64 k, i64 npoints,
+__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints,
                                                                  const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  Emit em,
                                                                  const double *__restrict__ nodes,
                                                                  const double *__restrict__ pts,
-                                                                 const int2 *__restrict__ q_in,
-                                                                 const int *__restrict__ q_in_count,
-                                                                 int2 *__restrict__ long_out,
-                                                                 int *__restrict__ long_count,
                                                                  int *__restrict__ slow_list,
                                                                  int *__restrict__ slow_count)
 {
-    __shared__ int2 s_queue[kPassBlock / 64][kWaveQueue];
-    __shared__ int2 s_long[kPassBlock / 64][kWaveQueue];
+    // [wave][tier][entry]: tier 0 ordinary retries, 1 solves that outlasted kPassIters, 2 ... kMidIters
+    __shared__ int2 s_queue0[kPassBlock / 64][kWaveQueue0];
+    __shared__ int2 s_queue12[kPassBlock / 64][2][kWaveQueue];
     const int lane = threadIdx.x & 63;
-    int2 *my_queue = s_queue[threadIdx.x >> 6];
-    int2 *my_long = s_long[threadIdx.x >> 6];
-    int held = 0;       // wave-uniform: unresolved targets waiting in my_queue
-    int held_long = 0;  // wave-uniform: targets whose current candidate needs the long solve
+    int2 *const my_q0 = s_queue0[threadIdx.x >> 6];
+    int2 *const my_q1 = s_queue12[threadIdx.x >> 6][0];
+    int2 *const my_q2 = s_queue12[threadIdx.x >> 6][1];
+    int held0 = 0, held1 = 0, held2 = 0;   // wave-uniform: entries waiting in each tier's queue
 
-    const i64 total = q_in ? (i64)*q_in_count : npoints;
-    const i64 nwaves = (i64)gridDim.x * (kPassBlock / 64);
-    const i64 wave = (i64)blockIdx.x * (kPassBlock / 64) + (threadIdx.x >> 6);
-    i64 next = wave * 64;  // first input entry of this wave's next fresh batch
+    // XCD-aware deal of the fresh batches.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+    // b + 8 share one) and each XCD has its own 4 MiB L2: with batches dealt round-robin over ALL waves every
+    // XCD walks the whole mesh and the connectivity and node arrays cross the fabric eight times (measured:
+    // 5-10 GB fetched per pass for 0.9 GB of mesh).  Here XCD x takes the x-th eighth of the targets (mesh
+    // nodes come in spatial order: a slab of the domain), its waves interleaved inside that range.
+    const int nx = gridDim.x < 8 ? (int)gridDim.x : 8;   // (small launches: one range per workgroup)
+    const int xcd = blockIdx.x % nx;
+    const i64 nbatches = (npoints + 63) / 64;
+    const i64 b_lo = nbatches * xcd / nx, b_hi = nbatches * (xcd + 1) / nx;
+    const i64 total = b_hi * 64 < npoints ? b_hi * 64 : npoints;       // end of this XCD's range
+    const i64 nwaves = (i64)((gridDim.x - xcd + nx - 1) / nx) * (kPassBlock / 64);   // waves of this XCD
+    const i64 wave = (i64)(blockIdx.x / nx) * (kPassBlock / 64) + (threadIdx.x >> 6);
+    i64 next = (b_lo + wave) * 64;  // first target of this wave's next fresh batch
     for (;;) {
-        // A wave always runs DENSE: as soon as 64 unresolved targets are waiting it retries those on
-        // their next candidate (most recent first: their point, candidate row and mesh lines are
-        // still in cache); otherwise it takes 64 fresh entries.
+        // A wave always runs DENSE: as soon as 64 entries are waiting in a queue it solves those (most
+        // recent first: their point, candidate row and mesh lines are still in cache), the slower tiers
+        // first; otherwise it takes 64 fresh targets.
         bool active;
         i64 i = 0;
         int j = 0;
-        int cap = kPassIters;  // retries from the wave's queue are ordinary solves
+        int tier = 0;          // whose cap this round's solves run under
         int lgG = 0;           // log2 of the lanes per target (only the drain rounds work ahead)
-        if (held >= 64) {
-            held -= 64;
-            const int2 e = my_queue[held + lane];
+        if (held2 >= 64 || held1 >= 64 || held0 >= 64) {
+            int from;
+            if (held2 >= 64) {
+                tier = 2;
+                from = held2 -= 64;
+            } else if (held1 >= 64) {
+                tier = 1;
+                from = held1 -= 64;
+            } else {
+                from = held0 -= 64;
+            }
+            const int2 e = (tier == 0 ? my_q0 : (tier == 1 ? my_q1 : my_q2))[from + lane];
             i = e.x;
             j = e.y;
             active = true;
         } else if (next < total) {
             const i64 q = next + lane;
             active = q < total;
-            if (active) {
-                if (q_in) {
-                    const int2 e = q_in[q];
-                    i = e.x;
-                    j = e.y;
-                } else {
-                    i = q;
-                }
-            }
+            if (active) i = q;
             next += nwaves * 64;
-            cap = fresh_cap;  // a long launch resumes parked solves with the reference's cap
-        } else if (held > 0) {
+        } else if (held0 > 0) {
             // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
             // handful of short rounds at the very end of the pass instead of another pass).  The idle
             // lanes work ahead: with at most 32 (16) targets left, 2 (4) lanes per target try its
             // next 2 (4) candidates at once, which shortens the chain of rounds a hard target needs;
             // the group then acts on the first candidate, in order, that is not a plain rejection.
-            lgG = held <= 16 ? 2 : (held <= 32 ? 1 : 0);
+            lgG = held0 <= 16 ? 2 : (held0 <= 32 ? 1 : 0);
             const int entry = lane >> lgG;
-            active = entry < held;
+            active = entry < held0;
             if (active) {
-                const int2 e = my_queue[entry];
+                const int2 e = my_q0[entry];
                 i = e.x;
                 j = e.y + (lane & ((1 << lgG) - 1));
             }
-            held = 0;
+            held0 = 0;
+        } else if (held1 > 0 || held2 > 0) {
+            // ... then the slow solves that are left, one lane each
+            tier = held1 > 0 ? 1 : 2;
+            active = lane < (tier == 1 ? held1 : held2);
+            if (active) {
+                const int2 e = (tier == 1 ? my_q1 : my_q2)[lane];
+                i = e.x;
+                j = e.y;
+            }
+            if (tier == 1) held1 = 0;
+            else held2 = 0;
         } else {
             break;
         }
+        const int cap = tier == 0 ? kPassIters : (tier == 1 ? kMidIters : kRefIters);
         wave_fence();  // the queue reads above happen before this round's appends
-        // outcome of this lane's candidate: 0 rejected, 1 accepted, 2 too slow for this cap (park),
+        // outcome of this lane's candidate: 0 rejected, 1 accepted, 2 too slow for this cap (next tier),
         // 3 no candidate left
         int outcome = 0;
         Corners c;
@@ -455,22 +492,18 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, 
                 outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
             } else if (have) {
                 double xi[3];
-                // A solve that has not converged within kPassIters iterations (p99 is 6) would hold the
-                // whole wave for up to 50; the target is parked, SAME candidate, for the next (long)
-                // launch, whose fresh entries run with the reference's own cap of 50 -- there slow solves
-                // only keep each other company, and "not converged" means the candidate is rejected.
                 const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap);
                 if (converged && in_hull(xi) && max_abs3(xi) < (1 + 0.025)) {
                     weights_hex8(xi, wt);
                     outcome = 1;
-                } else if (!converged && cap < 50) {
+                } else if (!converged && cap < kRefIters) {
                     outcome = 2;
                 }
             }
         }
         // the first lane of a target's group (the whole group when nobody works ahead) whose outcome is
         // not a rejection decides; if all rejected, the group's first lane moves on behind the group
-        bool requeue = false, go_long = false;
+        bool requeue = false, slower = false;
         int requeue_j = 0;
         {
             const int G = 1 << lgG;
@@ -481,7 +514,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, 
             const int g = lane - group_base;
             if (active && g == first) {
                 if (outcome == 1) emit_row(em, i, c.id, wt);
-                else if (outcome == 2) go_long = true;
+                else if (outcome == 2) slower = true;
                 else slow_list[atomicAdd(slow_count, 1)] = (int)i;
             } else if (active && first == G && g == 0) {
                 // every candidate of the group rejected (j is this lane's, the group's first)
@@ -493,41 +526,23 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(int fresh_cap, 
                 }
             }
         }
-        // unresolved targets go to the wave's own queue (slot = ballot prefix, no atomics); fewer than
-        // 64 were waiting and at most 64 are added, so kWaveQueue = 128 entries suffice
+        // unresolved targets go to the wave's own queues (slot = ballot prefix, no atomics); fewer than
+        // 64 were waiting in a queue and at most 64 are added, so kWaveQueue = 128 entries suffice
         const unsigned long long vote = __ballot(requeue);
-        if (requeue) my_queue[held + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, requeue_j);
-        held += __popcll(vote);
+        if (requeue) my_q0[held0 + __popcll(vote & ((1ull << lane) - 1ull))] = make_int2((int)i, requeue_j);
+        held0 += __popcll(vote);
         {
-            const unsigned long long lvote = __ballot(go_long);
-            if (go_long) my_long[held_long + __popcll(lvote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
-            held_long += __popcll(lvote);
-            if (held_long > kWaveQueue - 64) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(long_count, held_long);
-                base = __shfl(base, 0);
-                for (int t = lane; t < held_long; t += 64) long_out[base + t] = my_long[t];
-                held_long = 0;
-            }
+            // same candidate again, under the next tier's cap (a drain round with work-ahead groups runs
+            // under tier 0's cap, so its slow solves go to tier 1 like everybody else's)
+            const int up = tier == 0 ? 1 : 2;
+            const unsigned long long svote = __ballot(slower);
+            if (slower)
+                (up == 1 ? my_q1 + held1 : my_q2 + held2)[__popcll(svote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
+            if (up == 1) held1 += __popcll(svote);
+            else held2 += __popcll(svote);
         }
         wave_fence();
     }
-    if (held_long > 0) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(long_count, held_long);
-        base = __shfl(base, 0);
-        if (lane < held_long) long_out[base + lane] = my_long[lane];
-    }
-}
-
-__global__ __launch_bounds__(256) void queue_to_list_kernel(const int2 *__restrict__ q,
-                                                            const int *__restrict__ q_count,
-                                                            int *__restrict__ list, int *__restrict__ list_count)
-{
-    const i64 total = *q_count;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
-        list[atomicAdd(list_count, 1)] = q[t].x;
 }
 
 }  // namespace
@@ -546,22 +561,16 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
 
-    // the parked queues can hold every target in principle (a mesh on which no solve converges quickly)
-    int rc = mm_scratch_begin(ctx, 2 * mm_round256((size_t)npoints * sizeof(int2)) +
-                                       mm_round256((size_t)npoints * sizeof(int)) + 4096);
+    int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int)) + 4096);
     if (rc != MM_OK) return rc;
-    int2 *park[2];
-    park[0] = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
-    park[1] = (int2 *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int2));
     int *slow = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
-    int *counters = (int *)mm_scratch_take(ctx, 256);  // [8..8+kLongPasses] parked queues, [15] reference-order list
-    if (!park[0] || !park[1] || !slow || !counters) {
+    int *counters = (int *)mm_scratch_take(ctx, 256);  // [15] length of the reference-order list
+    if (!slow || !counters) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
-    constexpr int kLongPasses = 3;
     i64 resident = 0;
     {
         int per_cu = 0, cus = 0;
@@ -575,33 +584,22 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         resident = (i64)per_cu * cus;
     }
     const i64 grid = resident < full_grid ? resident : full_grid;
-#define MM_LAUNCH_PASS(FRESH_CAP, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT)                                                 \
-    do {                                                                                                             \
-        dim3 g_((unsigned)grid), b_(block);                                                                          \
-        if (conn_is_exodus)                                                                                          \
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g_, b_, 0, ctx->stream, FRESH_CAP, k, npoints, nn,   \
-                               conn, nelem, em, nodes, pts, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT, slow, slow_count); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g_, b_, 0, ctx->stream, FRESH_CAP, k, npoints, nn,  \
-                               conn, nelem, em, nodes, pts, QIN, QIN_COUNT, PARK_OUT, PARK_COUNT, slow, slow_count); \
-    } while (0)
-
-    // short launch (every Newton solve capped at kPassIters) over all targets.  Persistent waves:
-    // exactly as many workgroups as the device keeps resident, so that every wave lives for the whole
-    // pass and its private queue sees a long stream of targets.
+    // ONE launch over all targets.  Persistent waves: exactly as many workgroups as the device keeps
+    // resident, so that every wave lives for the whole pass and its private queues see a long stream
+    // of targets.
     mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
-    MM_LAUNCH_PASS(kPassIters, nullptr, nullptr, park[0], counters + 8);
-    mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
-    // long launches: the parked solves (~1 % of the targets) resume with the reference's cap of 50
-    // iterations; what follows for those targets is ordinary again (short solves from the wave's
-    // queue, parking anew what is slow).  Waves beyond a queue's length leave at once.
-    for (int p = 0; p < kLongPasses; ++p)
-        MM_LAUNCH_PASS(50, park[p & 1], counters + 8 + p, park[(p + 1) & 1], counters + 9 + p);
-#undef MM_LAUNCH_PASS
-    // still parked after that, or out of candidates without an acceptance: reference-order kernel
     {
-        hipLaunchKernelGGL(queue_to_list_kernel, dim3(64), dim3(block), 0, ctx->stream, park[kLongPasses & 1],
-                           counters + 8 + kLongPasses, slow, slow_count);
+        dim3 g_((unsigned)grid), b_(block);
+        if (conn_is_exodus)
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, slow, slow_count);
+        else
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
+                               nodes, pts, slow, slow_count);
+    }
+    mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
+    // out of candidates without an acceptance: reference-order kernel
+    {
         // lazily evaluated lists: these targets have only seen the nearest k of k_full candidates --
         // fetch their full lists now; the reference-order kernel starts again at candidate 0 anyway
         i64 k_slow = k;
@@ -629,8 +627,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         int h[16];
         MM_HIP_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[mm_locate] %lld targets; parked after each launch: %d %d %d %d; reference-order list %d\n",
-                (long long)npoints, h[8], h[9], h[10], h[11], h[15]);
+        fprintf(stderr, "[mm_locate] %lld targets; reference-order list %d\n", (long long)npoints, h[15]);
     }
     return MM_OK;
 }
