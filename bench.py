@@ -525,12 +525,17 @@ def run_rank(args):
         if world == 1:
             # PCIe-inclusive rate (never `value`): the same step fed from HOST arrays, i.e. what the
             # legacy host-pointer boundary costs: H2D of mesh + targets + field, D2H of the result
+            out_h = np.zeros((n_local, ncomp))          # the reference's callers pass zero-initialised outputs (cli.py:77-78)
+            ctx.interpolate_hex8_host(pa, ca, pb, fields, nelem_to_search=k, out=out_h)      # warm-up: device copies allocated
             t0 = time.perf_counter()
-            vals_h, _ = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=k)
-            vals_h = vals_h.numpy()
+            vals_h, _ = ctx.interpolate_hex8_host(pa, ca, pb, fields, nelem_to_search=k, out=out_h)
             t_host = time.perf_counter() - t0
-            line["host_arrays"] = {"ms": t_host * 1e3, "points_per_s": n_local / t_host,
-                                   "note": "one step fed from pageable host arrays (H2D + kernels + D2H); not `value`"}
+            nbytes = pa.nbytes + ca.nbytes + pb.nbytes + fields.nbytes + out_h.nbytes
+            line["host_arrays"] = {"ms": t_host * 1e3, "points_per_s": n_local / t_host, "bytes_over_pcie": nbytes,
+                                   "link_GBps_if_transfers_alone": round(nbytes / t_host / 1e9, 1),
+                                   "equals_resident_run": bool(np.array_equal(vals_h, t_out[:n_local].cpu().numpy())),
+                                   "note": "mm_interpolate_hex8_host: one step fed from pageable NumPy arrays (H2D on a second "
+                                           "stream beside the kernels + D2H), device copies cached in the context; not `value`"}
             del vals_h
         if world == 1 and not args.no_cpu_baseline:
             stride = args.cpu_sample_stride or max(1, n_local // 2_500_000)   # ~12 s of single-threaded CPU work

@@ -192,6 +192,17 @@ int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnod
                             int64_t npoints, const double *fields_d, int64_t ncomp,
                             int64_t nelem_to_search, double *out_d, int64_t *enc_d, double *w_d);
 
+/* The same path fed from HOST arrays -- what the reference's callers hold (NumPy arrays handed to
+ * centroid / cKDTree / triLinearInterpolator / np.sum at scripts/cli.py:62-100): nodes f64[nnodes][3],
+ * connectivity int64[nelem][8] (exodus order), points f64[npoints][3], fields f64[ncomp][nnodes], in place
+ * results out_h f64[npoints][ncomp] and (both or neither) enc_h int64[npoints][8], w_h f64[npoints][8].
+ * Uploads run on a second stream beside the kernels of the stage before (mesh -> centroids + grid |
+ * targets -> kNN | fields -> locate); the device copies live in the context and are reused by later calls. */
+int64_t mm_interpolate_hex8_host(mm_context *ctx, const double *nodes_h, int64_t nnodes,
+                                 const int64_t *connectivity_h, int64_t nelem, const double *points_h,
+                                 int64_t npoints, const double *fields_h, int64_t ncomp,
+                                 int64_t nelem_to_search, double *out_h, int64_t *enc_h, double *w_h);
+
 /* mm_interpolate_hex8 evaluates its candidate lists lazily (default on): the locate stage walks a
  * target's candidates in kNN order and stops at the first acceptance (1.6 candidates per target on
  * mesh-like inputs), so the pipeline first asks the kNN stage for the 8 nearest only and computes

@@ -50,9 +50,9 @@ def interpolate_operator(mesh_a: HexMesh, points, nelem_to_search=20, context=No
     ctx = context or default_context()
     points = np.ascontiguousarray(points, dtype=np.float64)
     field = np.zeros((1, mesh_a.npoint))
-    _, enc, w, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, points, field,
-                                              nelem_to_search=nelem_to_search, want_operator=True)
-    return enc.numpy(), w.numpy(), nfailed
+    _, enc, w, nfailed = ctx.interpolate_hex8_host(mesh_a.points, mesh_a.connectivity, points, field,
+                                                   nelem_to_search=nelem_to_search, want_operator=True)
+    return enc, w, nfailed
 
 
 def apply_operator(mesh_a: HexMesh, enclosing_elem_node_indices, weights, params, context=None):
@@ -113,9 +113,8 @@ def interpolate_mesh_a_to_b(mesh_a: HexMesh, mesh_b: HexMesh, params=("TTI",), c
         params = list(TTI_PARAMS)
     ctx = context or default_context()
     nelem_to_search = 20  # reference cli.py:69
-    values, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, mesh_b.points,
-                                           mesh_a.fields_matrix(params), nelem_to_search=nelem_to_search)
-    values = values.numpy()
+    values, nfailed = ctx.interpolate_hex8_host(mesh_a.points, mesh_a.connectivity, mesh_b.points,
+                                                mesh_a.fields_matrix(params), nelem_to_search=nelem_to_search)
     for i, param in enumerate(params):
         mesh_b.attach_field(param, values[:, i])
     assert nfailed == 0, f"{nfailed} points could not be interpolated."
@@ -134,12 +133,12 @@ def interpolate_to_points(mesh, points, params_to_interp, make_spherical=False, 
         points = latlondepth_to_xyz(points)
     ctx = context or default_context()
     points = np.ascontiguousarray(points, dtype=np.float64)
-    vals, nfailed = ctx.interpolate_hex8(mesh.points, mesh.connectivity, points,
-                                         mesh.fields_matrix(params_to_interp), nelem_to_search=nelem_to_search)
+    vals, nfailed = ctx.interpolate_hex8_host(mesh.points, mesh.connectivity, points,
+                                              mesh.fields_matrix(params_to_interp), nelem_to_search=nelem_to_search)
     if nfailed > 0:
         print(nfailed, "points could not find an enclosing element. These points will be set to zero. "
                        "Please check your domain or the interpolation tuning parameters")
-    return vals.numpy()
+    return vals
 
 
 def interpolate_to_mesh(old_mesh, new_mesh, params_to_interp=("VSV", "VSH", "VPV", "VPH"), context=None):

@@ -48,6 +48,11 @@ enum mm_buffer_slot {
     MM_BUF_SORTED_XYZ,
     MM_BUF_NN_FULL,
     MM_BUF_BOX_PARTIAL,
+    MM_BUF_H_NODES,                       // device copies of host arrays (mm_interpolate_hex8_host)
+    MM_BUF_H_CONN,
+    MM_BUF_H_POINTS,
+    MM_BUF_H_FIELDS,
+    MM_BUF_H_OUT,
     MM_BUF_LEVELS,                        // density levels of the kNN grid: {cell_start, sorted_xyz} per level
     MM_BUF_COUNT = MM_BUF_LEVELS + 2 * 8
 };
@@ -69,6 +74,8 @@ struct mm_context {
     bool ev_used[MM_STAGE_COUNT];
     bool ev_created = false;
     hipEvent_t ev_misc = nullptr;   // host waits on small readbacks while later work stays queued
+    hipStream_t copy_stream = nullptr;   // host-array entry points: uploads run beside the kernels (created on first use)
+    hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr};
 };
 
 // Reserve `total` bytes of scratch for the current call (may reallocate), then carve with

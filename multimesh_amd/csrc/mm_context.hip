@@ -74,6 +74,9 @@ extern "C" void mm_context_destroy(mm_context *ctx)
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev_misc) (void)hipEventDestroy(ctx->ev_misc);
+    for (int q = 0; q < 3; ++q)
+        if (ctx->ev_copy[q]) (void)hipEventDestroy(ctx->ev_copy[q]);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ev_created)
         for (int s = 0; s < MM_STAGE_COUNT; ++s) {
             (void)hipEventDestroy(ctx->ev_begin[s]);

@@ -25,10 +25,31 @@ static const int64_t kFuseGatherMaxComp = 3;   // measured at 10M targets: 1: -0
 // Intermediates (centroids, candidate lists, and the operator when the caller does not ask for
 // it) live in caller-invisible device memory owned by this call.
 // -----------------------------------------------------------------------------------------
-extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnodes,
-                                       const int64_t *conn_d, int64_t nelem, const double *points_d,
-                                       int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
-                                       double *out_d, int64_t *enc_d, double *w_d)
+// Host arrays behind the device-pointer pipeline (mm_interpolate_hex8_host): each upload is issued on the
+// context's copy stream just before the stage that needs it, so that it runs beside the kernels of the
+// stage before (mesh -> centroids + grid build | targets -> kNN | fields -> locate).  Uploads from
+// pageable memory block the host thread, which is why they are interleaved with the (asynchronous) launches
+// here instead of being queued up front.
+struct mm_host_feed {
+    const void *src[4];   // nodes, connectivity, points, fields (host)
+    void *dst[4];         // their device copies (context buffer cache)
+    size_t bytes[4];
+};
+
+static int feed_upload(mm_context *ctx, const mm_host_feed *feed, int first, int last, int event)
+{
+    for (int a = first; a <= last; ++a)
+        if (feed->bytes[a])
+            MM_HIP_CHECK(hipMemcpyAsync(feed->dst[a], feed->src[a], feed->bytes[a], hipMemcpyHostToDevice, ctx->copy_stream));
+    MM_HIP_CHECK(hipEventRecord(ctx->ev_copy[event], ctx->copy_stream));
+    MM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy[event], 0));
+    return MM_OK;
+}
+
+static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int64_t nnodes,
+                                     const int64_t *conn_d, int64_t nelem, const double *points_d,
+                                     int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
+                                     double *out_d, int64_t *enc_d, double *w_d, const mm_host_feed *feed)
 {
     MM_REQUIRE(ctx != nullptr, "ctx is null");
     MM_REQUIRE(nnodes >= 1 && nelem >= 1, "empty source mesh");
@@ -91,6 +112,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     // scripts/cli.py:77-78): the reference-order locate kernel, the only place a point can fail,
     // writes them (no 1.3 GB memset up front)
 
+    if (feed && (rc = feed_upload(ctx, feed, 0, 1, 0)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
     rc = mm_launch_centroid_bbox(ctx, nelem, (const i64 *)conn_d, nodes_d, cen, box_partial, kBoxBlocks);
     mm_stage_end(ctx, MM_STAGE_CENTROID);
@@ -101,6 +123,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     if (rc != MM_OK) { result = rc; goto done; }
 
+    if (feed && (rc = feed_upload(ctx, feed, 2, 2, 1)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
     rc = mm_knn_query_impl(ctx, index, points_d, npoints, kq, nn, nullptr, true);
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
@@ -108,6 +131,7 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
 
     // locate + gather: scripts/cli.py:86-100.  MM_STAGE_GATHER stays empty on this path (mm_gather is
     // the stand-alone A9 for callers that keep the operator).
+    if (feed && (rc = feed_upload(ctx, feed, 3, 3, 2)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_LOCATE);
     lazy.index = index;
     lazy.k_full = k;
@@ -135,6 +159,80 @@ done:
     if (index) mm_knn_destroy(nullptr, index);  // borrowed arrays stay in the context cache
     return result;
 #undef MM_PIPE_FAIL
+}
+
+extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnodes,
+                                       const int64_t *conn_d, int64_t nelem, const double *points_d,
+                                       int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
+                                       double *out_d, int64_t *enc_d, double *w_d)
+{
+    return interpolate_hex8_impl(ctx, nodes_d, nnodes, conn_d, nelem, points_d, npoints, fields_d, ncomp, k, out_d,
+                                 enc_d, w_d, nullptr);
+}
+
+// The same path fed from HOST arrays (what the reference's callers hold: NumPy arrays, scripts/cli.py:62-100):
+// uploads overlapped with the kernels as described at mm_host_feed, device copies kept in the context's
+// grow-only buffer cache (no hipMalloc / hipFree per call), results copied back into the caller's arrays.
+// out_h f64[npoints][ncomp]; enc_h / w_h (both or neither) receive the operator rows.
+extern "C" int64_t mm_interpolate_hex8_host(mm_context *ctx, const double *nodes_h, int64_t nnodes,
+                                            const int64_t *conn_h, int64_t nelem, const double *points_h,
+                                            int64_t npoints, const double *fields_h, int64_t ncomp, int64_t k,
+                                            double *out_h, int64_t *enc_h, double *w_h)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(nnodes >= 1 && nelem >= 1, "empty source mesh");
+    MM_REQUIRE(npoints >= 0 && ncomp >= 0, "negative size");
+    MM_REQUIRE(nodes_h && conn_h, "null mesh array");
+    MM_REQUIRE(npoints == 0 || points_h, "null target array");
+    MM_REQUIRE(ncomp == 0 || out_h == nullptr || fields_h, "null field array");
+    MM_REQUIRE((enc_h == nullptr) == (w_h == nullptr), "enc and w go together");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (npoints == 0) return 0;
+    if (!ctx->copy_stream) {
+        MM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int q = 0; q < 3; ++q) MM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_copy[q], hipEventDisableTiming));
+    }
+    const bool want_values = out_h && ncomp > 0;
+    mm_host_feed feed;
+    feed.src[0] = nodes_h;
+    feed.bytes[0] = (size_t)nnodes * 3 * sizeof(double);
+    feed.src[1] = conn_h;
+    feed.bytes[1] = (size_t)nelem * 8 * sizeof(int64_t);
+    feed.src[2] = points_h;
+    feed.bytes[2] = (size_t)npoints * 3 * sizeof(double);
+    feed.src[3] = fields_h;
+    feed.bytes[3] = want_values ? (size_t)ncomp * (size_t)nnodes * sizeof(double) : 0;
+    static const int slot[4] = {MM_BUF_H_NODES, MM_BUF_H_CONN, MM_BUF_H_POINTS, MM_BUF_H_FIELDS};
+    for (int a = 0; a < 4; ++a) {
+        int rc = mm_buffer_get(ctx, slot[a], feed.bytes[a], &feed.dst[a]);
+        if (rc != MM_OK) return rc;
+    }
+    double *out_d = nullptr;
+    i64 *enc_d = nullptr;
+    double *w_d = nullptr;
+    if (want_values) {
+        int rc = mm_buffer_get(ctx, MM_BUF_H_OUT, (size_t)npoints * (size_t)ncomp * sizeof(double), (void **)&out_d);
+        if (rc != MM_OK) return rc;
+    }
+    if (enc_h) {
+        int rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * 8 * sizeof(i64), (void **)&enc_d);
+        if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * 8 * sizeof(double), (void **)&w_d);
+        if (rc != MM_OK) return rc;
+    }
+    // the uploads overwrite buffers the previous call's kernels may still read
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t nfailed = interpolate_hex8_impl(ctx, (const double *)feed.dst[0], nnodes, (const int64_t *)feed.dst[1], nelem,
+                                                  (const double *)feed.dst[2], npoints, (const double *)feed.dst[3],
+                                                  want_values ? ncomp : 0, k, out_d, (int64_t *)enc_d, w_d, &feed);
+    if (nfailed < 0) return nfailed;
+    if (want_values)
+        MM_HIP_CHECK(hipMemcpyAsync(out_h, out_d, (size_t)npoints * (size_t)ncomp * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (enc_h) {
+        MM_HIP_CHECK(hipMemcpyAsync(enc_h, enc_d, (size_t)npoints * 8 * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        MM_HIP_CHECK(hipMemcpyAsync(w_h, w_d, (size_t)npoints * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return nfailed;
 }
 
 // -----------------------------------------------------------------------------------------

@@ -339,6 +339,38 @@ class Context:
             return out, enc, w, int(nf)
         return out, int(nf)
 
+    def interpolate_hex8_host(self, nodes, connectivity, points, fields, nelem_to_search=20, want_operator=False,
+                              out=None):
+        """:meth:`interpolate_hex8` for NumPy arrays on the host (reference scripts/cli.py:62-100 holds
+        nothing else): uploads overlapped with the kernels, device copies cached in the context.
+        Returns NumPy arrays: (values f64[N,C], nfailed) or (values, enc, weights, nfailed)."""
+        nod = np.ascontiguousarray(nodes, dtype=np.float64)
+        conn = np.ascontiguousarray(connectivity, dtype=np.int64)
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        f = np.ascontiguousarray(fields, dtype=np.float64)
+        if f.ndim == 1:
+            f = f[None]
+        if nod.ndim != 2 or nod.shape[1] != 3 or conn.ndim != 2 or conn.shape[1] != 8 or pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("need nodes[M,3], connectivity[E,8], points[N,3]")
+        if f.shape[1] != nod.shape[0]:
+            raise ValueError("fields must be [C, number of nodes]")
+        n, ncomp = pts.shape[0], f.shape[0]
+        if out is None:
+            out = np.empty((n, ncomp), dtype=np.float64)
+        elif out.shape != (n, ncomp) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous f64[N, C] array")
+        enc = np.empty((n, 8), dtype=np.int64) if want_operator else None
+        w = np.empty((n, 8), dtype=np.float64) if want_operator else None
+        nf = check(self.lib.mm_interpolate_hex8_host(self.handle, nod.ctypes.data, nod.shape[0], conn.ctypes.data,
+                                                     conn.shape[0], pts.ctypes.data, n, f.ctypes.data, ncomp,
+                                                     nelem_to_search, out.ctypes.data,
+                                                     enc.ctypes.data if want_operator else None,
+                                                     w.ctypes.data if want_operator else None),
+                   "mm_interpolate_hex8_host")
+        if want_operator:
+            return out, enc, w, int(nf)
+        return out, int(nf)
+
     # ---- A11 ----------------------------------------------------------------------------
     def unique_points(self, points):
         """``np.unique(points, axis=0, return_inverse=True)`` (reference utils.py:484-488) on the

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "mm_context_create", "mm_context_destroy", "mm_synchronize",
     "mm_device_alloc", "mm_device_free", "mm_copy_h2d", "mm_copy_d2h", "mm_memset",
     "mm_centroid", "mm_knn_build", "mm_knn_query", "mm_knn_destroy",
-    "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_locate_gll", "mm_gather_elem",
+    "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_interpolate_hex8_host", "mm_locate_gll", "mm_gather_elem",
     "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
 )
 
@@ -111,6 +111,9 @@ def load_lib():
     lib.mm_gather.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, C.c_int]
     lib.mm_interpolate_hex8.restype = C.c_int64
     lib.mm_interpolate_hex8.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
+                                        C.c_int64, vp, vp, vp]
+    lib.mm_interpolate_hex8_host.restype = C.c_int64
+    lib.mm_interpolate_hex8_host.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
                                         C.c_int64, vp, vp, vp]
     lib.mm_locate_gll.restype = C.c_int64
     lib.mm_locate_gll.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp, C.c_int64, vp, C.c_double,

@@ -409,6 +409,30 @@ def test_cfg1_full_size_2d_through_the_api(order):
     assert np.abs(out[1] - synth.field_linear(tgt)).max() < 1e-11
 
 
+def test_host_array_entry_equals_the_resident_pipeline(ctx):
+    # mm_interpolate_hex8_host (uploads overlapped with the kernels, device copies cached in the context):
+    # same bits as the resident-array entry and the oracle, across calls of growing and shrinking size,
+    # with and without the operator, with more components than the fused gather takes
+    for n_src, n_tgt, ncomp in ((13, 17, 1), (31, 29, 5), (9, 40, 3), (31, 29, 2)):
+        pa, ca = synth.hex_mesh(n_src, seed=1)
+        pb, _ = synth.hex_mesh(n_tgt, seed=7)
+        pb = np.concatenate([pb, [[1.7, 0.5, 0.5], [-0.4, 2.0, 0.1]]])          # two targets outside: they fail
+        fields = np.stack([synth.field_linear(pa), synth.field_smooth(pa), synth.field_xyz(pa),
+                           synth.field_linear(pa) ** 2, -synth.field_smooth(pa)])[:ncomp]
+        nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20)
+        enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+        vals_o = O.gather(fields, enc_o, w_o)
+        v_dev, nf_dev = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+        v1, nf1 = ctx.interpolate_hex8_host(pa, ca, pb, fields, nelem_to_search=20)
+        out = np.full((len(pb), ncomp), 123.0)
+        v2, enc, w, nf2 = ctx.interpolate_hex8_host(pa, ca, pb, fields, nelem_to_search=20, want_operator=True, out=out)
+        assert v2 is out and nf1 == nf2 == nf_dev == nf_o == 2
+        assert np.array_equal(v1, vals_o) and np.array_equal(v2, vals_o) and np.array_equal(v_dev.numpy(), vals_o)
+        assert np.array_equal(enc, enc_o) and np.array_equal(w, w_o)
+    with pytest.raises(ValueError):
+        ctx.interpolate_hex8_host(pa, ca, pb, fields[:, :5])
+
+
 def test_graded_meshes_through_the_pipeline(ctx):
     # meshes refined towards a corner (node coordinates u -> u^2.2 per axis: element sizes span three
     # orders of magnitude, so the centroid cloud needs several density levels), source and target of
