@@ -182,6 +182,24 @@ int64_t mm_interpolate_gll(mm_context *ctx, int order, int dim, const double *gl
 int64_t mm_unique_points(mm_context *ctx, const double *points_d, int64_t npoints, int64_t dim,
                          double *unique_d, int64_t *inverse_d);
 
+/* Layer-aware GLL drivers (reference components/interpolator.py:1047-1082): the scatter-back
+ *     new_field[mask[layer]] = values[inverse].reshape(...)            (:1079-1081)
+ * on the device.  values_d f64[nunique][ncomp] (what mm_interpolate_gll returns for the layer's unique target
+ * points), inverse_d int64[nmasked * P] (mm_unique_points of the layer's element-nodal target points),
+ * elem_ids_d int64[nmasked] (the layer's target elements); out_d f64[ncomp][nelem_out][P] receives
+ * out[c][elem_ids[m]][p] = values[inverse[m * P + p]][c]; other rows are left alone. */
+int mm_scatter_elements(mm_context *ctx, const double *values_d, int64_t nunique, int64_t ncomp,
+                        const int64_t *inverse_d, const int64_t *elem_ids_d, int64_t nmasked, int64_t P,
+                        int64_t nelem_out, double *out_d);
+
+/* The fluid/solid fix-up of gll_2_gll (reference components/interpolator.py:829-841) on element data
+ * values_d / previous_d f64[nelem][ncomp][P]: elements with solid_d[e] == 0 get their previous values back
+ * ("values[~solid_elements] = new_values[~solid_elements]"), and so does a solid element whose parameter
+ * vs_index is exactly 0.0 at any point.  Returns the number of SOLID elements restored, or a negative MM_ERR_*. */
+int64_t mm_fluid_solid_fix(mm_context *ctx, double *values_d, const double *previous_d,
+                           const unsigned char *solid_d, int64_t nelem, int64_t ncomp, int64_t P,
+                           int64_t vs_index);
+
 /* The whole hot path of reference scripts/cli.py:62-100 on resident arrays:
  * centroid -> search grid -> kNN -> locate -> gather.  connectivity_d is the mesh's own
  * (exodus-order) hex8 connectivity.  enc_d / w_d (nullable) receive the interpolation

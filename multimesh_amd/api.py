@@ -15,6 +15,7 @@ SURVEY.md §8 row they wait for.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -259,6 +260,117 @@ def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to
     return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(list(params)), tgt.shape[0], tgt.shape[1])
 
 
+def assess_layers(layer_ids, layers):
+    """The list form of the reference's ``utils._assess_layers`` (utils.py:382-408): ``layers`` = "all" or a
+    list of layer numbers that must lie within the mesh's own; returned in descending order for "all", as the
+    reference sorts them.  The Earth presets ("crust", "mantle", "core", "nocore": utils.py:413-440) need the
+    mesh's moho / fluid metadata and are not part of the hot path."""
+    mesh_layers = np.sort(np.unique(np.asarray(layer_ids)))[::-1].astype(int)
+    if isinstance(layers, str):
+        if layers != "all":
+            raise ValueError("layers must be 'all' or a list of layer numbers (the Earth presets need mesh metadata)")
+        return [int(x) for x in mesh_layers]
+    layers = [int(x) for x in np.atleast_1d(layers)]
+    if max(layers) > mesh_layers.max() or min(layers) < mesh_layers.min():
+        raise ValueError("Requested layers not in mesh")
+    return layers
+
+
+def load_stored_layer_operator(stored_array):
+    """``interp_info`` of the layered drivers (reference interpolator.py:1035-1044: ``coeffs/<layer>`` and
+    ``elements/<layer>`` datasets of interp_info.h5); an ``.npz`` with the same keys since h5py is absent."""
+    path = os.path.join(stored_array, "interp_info.npz") if stored_array else None
+    if not path or not os.path.exists(path):
+        return None
+    with np.load(path) as f:
+        return ({k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("elements/")},
+                {k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("coeffs/")})
+
+
+def save_stored_layer_operator(stored_array, elements, coeffs):
+    os.makedirs(stored_array, exist_ok=True)
+    arrays = {f"elements/{k}": v for k, v in elements.items()}
+    arrays.update({f"coeffs/{k}": v for k, v in coeffs.items()})
+    np.savez(os.path.join(stored_array, "interp_info.npz"), **arrays)
+
+
+def interpolate_gll_to_gll_layered(mesh_a: GllMesh, layer_a, target_gll_points, layer_b, params_to_interp,
+                                   layers="all", nelem_to_search=30, tolerance=1.05, stored_array=None,
+                                   existing=None, context=None):
+    """The array core of ``gll_2_gll_layered_multi_two`` (reference interpolator.py:980-1082): for every
+    layer, the unique element-nodal points of the TARGET elements of that layer are located among the
+    SOURCE elements of the same layer only (a tree over just their centroids, :1053), with
+    ``snap_to_nearest=True`` (:1057), and the values are scattered back into the rows of those target
+    elements (:1079-1081).  ``layer_a`` / ``layer_b``: the ``layer`` elemental field of the two meshes.
+
+    Per layer everything runs on the device: ``mm_unique_points`` -> ``mm_interpolate_gll`` on the layer's
+    sub-meshes -> ``mm_scatter_elements``.  ``stored_array``: the per-layer operator is kept as
+    ``interp_info.npz`` (``coeffs/<layer>``, ``elements/<layer>``) and re-applied when it exists.
+    Returns f64[C, E_t, P_t]; rows of target elements outside ``layers`` keep ``existing`` (zeros when not
+    given), like the fields of the reference's ``new_mesh``."""
+    ctx = context or default_context()
+    tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
+    layer_a, layer_b = np.asarray(layer_a), np.asarray(layer_b)
+    if layer_a.shape != (mesh_a.nelem,) or layer_b.shape != (tgt.shape[0],):
+        raise ValueError("layer_a / layer_b must hold one layer number per element")
+    params = list(params_to_interp)
+    n_t, p_t, dim = tgt.shape
+    out = ctx.zeros((len(params), n_t, p_t), np.float64) if existing is None else \
+        ctx.to_device(np.ascontiguousarray(existing, dtype=np.float64))
+    if out.shape != (len(params), n_t, p_t):
+        raise ValueError("existing must be [C, E_t, P_t]")
+    stored = load_stored_layer_operator(stored_array)
+    if stored is not None:
+        print("No need for looping, we have the matrices")
+    elements, coeffs = {}, {}
+    for layer in assess_layers(layer_a, layers):
+        key = str(layer)
+        src_mask, tgt_mask = layer_a == layer, layer_b == layer
+        if not tgt_mask.any():
+            continue
+        if not src_mask.any():
+            raise ValueError(f"layer {layer} has target elements but no source elements")
+        src = np.ascontiguousarray(mesh_a.gll_points[src_mask])
+        fields = np.stack([mesh_a.element_nodal_fields[p][src_mask] for p in params])
+        uniq, inv = ctx.unique_points(np.ascontiguousarray(tgt[tgt_mask]).reshape(-1, dim))
+        if stored is not None:
+            elements[key], coeffs[key] = stored[0][key], stored[1][key]
+            vals = ctx.gather_elem(fields, elements[key], coeffs[key])
+        else:
+            print("interpolating layer", layer, "...")
+            if stored_array:
+                vals, el, co, missing = ctx.interpolate_gll(mesh_a.shape_order, src, uniq, fields,
+                                                            nelem_to_search=nelem_to_search, tolerance=tolerance,
+                                                            snap_to_nearest=True, want_operator=True)
+                elements[key], coeffs[key] = el.numpy(), co.numpy()
+            else:
+                vals, missing = ctx.interpolate_gll(mesh_a.shape_order, src, uniq, fields,
+                                                    nelem_to_search=nelem_to_search, tolerance=tolerance,
+                                                    snap_to_nearest=True)
+            if missing:
+                print(missing, "points of layer", layer, "could not find an enclosing element")
+        ctx.scatter_elements(vals, inv, np.nonzero(tgt_mask)[0].astype(np.int64), out)
+    if stored is None and stored_array:
+        print("Saving interpolation matrices")
+        save_stored_layer_operator(stored_array, elements, coeffs)
+    return out.numpy()
+
+
+def fix_fluid_solid(values, previous_values, solid_elements, parameters, context=None):
+    """The fluid/solid fix-up at the end of ``gll_2_gll`` (reference interpolator.py:829-841) as a device
+    pass: ``values`` / ``previous_values`` f64[E, nparam, P] (the ``MODEL/data`` layout), ``solid_elements``
+    bool[E].  Fluid elements keep their previous values; so does a solid element whose VS (or VSV) came
+    out exactly zero somewhere.  Returns the fixed array."""
+    ctx = context or default_context()
+    parameters = list(parameters)
+    vs_index = parameters.index("VS") if "VS" in parameters else parameters.index("VSV")
+    v = ctx.to_device(np.ascontiguousarray(values, dtype=np.float64))
+    print("If any fluid values accidentally went to the solid part we fix it")
+    ctx.fluid_solid_fix(v, np.ascontiguousarray(previous_values, dtype=np.float64), np.asarray(solid_elements, dtype=bool),
+                        vs_index)
+    return v.numpy()
+
+
 def find_gll_centroids(gll_coordinates, dimensions=3):
     """The reference's ``_find_gll_centroids`` (interpolator.py:1389-1406): per-dimension
     ``np.mean(gll_coordinates[:, :, d], axis=1)`` -- NumPy's pairwise row sum over the strided view,
@@ -325,8 +437,8 @@ def _gll(name, row):
 
 exodus_2_gll = _gll("exodus_2_gll", "§8f-2 (file I/O) -- array core: interpolate_hex8_to_gll")
 gll_2_gll = _gll("gll_2_gll", "A10 -- array core: interpolate_gll_to_gll; file I/O is §8f-2")
-gll_2_gll_layered = _gll("gll_2_gll_layered", "A10 / §8f-4")
-gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "A10 / §8f-4")
-gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "A10 / §8f-4")
+gll_2_gll_layered = _gll("gll_2_gll_layered", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
+gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
+gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
 gll_2_exodus = _gll("gll_2_exodus", "§8f-2 (file I/O) -- array core: interpolate_gll_to_nodes")
 query_model = _gll("query_model", "§8f-2 (file I/O) -- array core: query_gll_model")

@@ -16,7 +16,7 @@ import numpy as np
 
 from .helpers import MM_KNN_MAX_K, STAGES, MultiMeshHipError, check, load_lib
 
-_NP2ITEM = {np.dtype(np.float64): 8, np.dtype(np.int64): 8, np.dtype(np.int32): 4}
+_NP2ITEM = {np.dtype(np.float64): 8, np.dtype(np.int64): 8, np.dtype(np.int32): 4, np.dtype(np.uint8): 1}
 
 
 class DeviceArray:
@@ -370,6 +370,35 @@ class Context:
         if want_operator:
             return out, enc, w, int(nf)
         return out, int(nf)
+
+    # ---- section 8f-4: device passes of the layer-aware drivers ------------------------------------
+    def scatter_elements(self, values, inverse, elem_ids, out):
+        """``out[:, elem_ids] = values[inverse].reshape(len(elem_ids), P, C)`` transposed to the element-nodal
+        layout (reference interpolator.py:1079-1081): values f64[U, C], inverse int64[len(elem_ids) * P],
+        out f64[C, E, P] (updated in place on the device)."""
+        v = self.asdevice(values, np.float64)
+        inv = self.asdevice(inverse, np.int64)
+        ids = self.asdevice(elem_ids, np.int64)
+        o = self.asdevice(out, np.float64)
+        ncomp, nelem_out, P = o.shape
+        if v.shape[1] != ncomp or inv.size != ids.size * P:
+            raise ValueError("need values[U, C], inverse[len(elem_ids) * P], out[C, E, P]")
+        check(self.lib.mm_scatter_elements(self.handle, v.ptr, v.shape[0], ncomp, inv.ptr, ids.ptr, ids.size, P,
+                                           nelem_out, o.ptr), "mm_scatter_elements")
+        return o
+
+    def fluid_solid_fix(self, values, previous, solid, vs_index):
+        """The fix-up of reference interpolator.py:829-841 on values f64[E, C, P] (in place on the device):
+        fluid elements and solid elements with a zero shear velocity get ``previous`` back.  Returns the
+        number of solid elements restored."""
+        v = self.asdevice(values, np.float64)
+        prev = self.asdevice(previous, np.float64)
+        sol = self.asdevice(np.ascontiguousarray(solid, dtype=np.uint8), np.uint8)
+        nelem, ncomp, P = v.shape
+        if prev.shape != v.shape or sol.size != nelem:
+            raise ValueError("need values[E, C, P], previous[E, C, P], solid[E]")
+        return int(check(self.lib.mm_fluid_solid_fix(self.handle, v.ptr, prev.ptr, sol.ptr, nelem, ncomp, P, int(vs_index)),
+                         "mm_fluid_solid_fix"))
 
     # ---- A11 ----------------------------------------------------------------------------
     def unique_points(self, points):

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "mm_device_alloc", "mm_device_free", "mm_copy_h2d", "mm_copy_d2h", "mm_memset",
     "mm_centroid", "mm_knn_build", "mm_knn_query", "mm_knn_destroy",
     "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_interpolate_hex8_host", "mm_locate_gll", "mm_gather_elem",
-    "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
+    "mm_scatter_elements", "mm_fluid_solid_fix", "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
 )
 
 
@@ -109,6 +109,10 @@ def load_lib():
     lib.mm_locate_hex8.argtypes = [vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int, vp, vp, vp, vp]
     lib.mm_gather.restype = C.c_int
     lib.mm_gather.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, C.c_int]
+    lib.mm_scatter_elements.restype = C.c_int
+    lib.mm_scatter_elements.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp]
+    lib.mm_fluid_solid_fix.restype = C.c_int64
+    lib.mm_fluid_solid_fix.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     lib.mm_interpolate_hex8.restype = C.c_int64
     lib.mm_interpolate_hex8.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
                                         C.c_int64, vp, vp, vp]

@@ -246,3 +246,80 @@ def test_query_gll_model_array_core():
     want = np.sum(data[elem] * coeffs[:, None, :], axis=2)
     assert np.array_equal(vals, want)
     assert np.abs(vals[:, 0] - synth.field_linear(pts)).max() < 1e-11
+
+
+# ------------------------------------------------------------------------------- section 8f-4: layers
+def _layered_oracle(src, layer_a, fields, tgt, layer_b, layers, order, k, tol):
+    """The reference's loop over layers (interpolator.py:1047-1082) spelled out with NumPy + the CPU oracle."""
+    out = np.zeros((fields.shape[0],) + tgt.shape[:2])
+    ops = {}
+    for layer in layers:
+        sm, tm = layer_a == layer, layer_b == layer
+        nodes = tgt[tm]
+        uniq, inv = np.unique(nodes.reshape(-1, nodes.shape[2]), return_inverse=True, axis=0)   # utils.py:506-510
+        nn, _ = O.knn_ckdtree(src[sm].mean(axis=1), uniq, k)                                     # tree over the masked centroids
+        elem, co, _ = O.locate_gll(order, nn, np.ascontiguousarray(src[sm]), uniq, tolerance=tol, snap_to_nearest=True)
+        vals = O.gather_elem(np.ascontiguousarray(fields[:, sm]), elem, co)                      # [U, C]
+        out[:, tm] = vals[inv.reshape(-1)].reshape(nodes.shape[0], nodes.shape[1], -1).transpose(2, 0, 1)
+        ops[str(layer)] = (elem, co)
+    return out, ops
+
+
+@pytest.mark.gpu
+def test_layered_gll_to_gll_equals_the_per_layer_loop(tmp_path):
+    # a 3-layer synthetic "Earth": layers are slabs in z; source and target meshes of different resolution, so
+    # that target points near a layer boundary have nearest source centroids in the WRONG layer -- which the
+    # per-layer trees must never offer
+    from multimesh_amd import api, synth
+
+    order = 2
+    src = synth.gll_mesh(10, order, seed=1)                      # 9^3 elements
+    tgt = synth.gll_mesh(13, order, seed=7)                      # 12^3 elements
+    layer_a = np.minimum((src.mean(axis=1)[:, 2] * 3).astype(int), 2)
+    layer_b = np.minimum((tgt.mean(axis=1)[:, 2] * 3).astype(int), 2)
+    fields = {"VSV": 1.0 + synth.field_smooth(src.reshape(-1, 3)).reshape(src.shape[:2]) ** 2 + layer_a[:, None],
+              "RHO": synth.field_linear(src) + 10.0 * layer_a[:, None]}
+    mesh = api.GllMesh(src, order, fields)
+    fstack = np.stack([fields["VSV"], fields["RHO"]])
+    want, ops = _layered_oracle(src, layer_a, fstack, tgt, layer_b, [2, 1, 0], order, 30, 1.05)
+    store = str(tmp_path / "op")
+    got = api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV", "RHO"], layers="all", stored_array=store)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # the stored per-layer operator (interp_info: coeffs/<layer>, elements/<layer>) equals the oracle's and is re-applied
+    el, co = api.load_stored_layer_operator(store)
+    for key, (e_o, c_o) in ops.items():
+        assert np.array_equal(el[key], e_o) and np.array_equal(co[key], c_o)
+    again = api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV", "RHO"], layers="all", stored_array=store)
+    assert np.array_equal(again, want)
+    # a subset of the layers: the other target elements keep what they had
+    existing = np.full(want.shape, -7.0)
+    part = api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV", "RHO"], layers=[1], existing=existing)
+    assert np.array_equal(part[:, layer_b == 1], want[:, layer_b == 1]) and np.all(part[:, layer_b != 1] == -7.0)
+    # every value comes from the target's own layer: RHO carries 10 * layer (points that stick out of their layer
+    # are snapped to its nearest element, xi clipped to +-1.02 as in the reference: not the exact linear value)
+    assert np.array_equal(np.round((got[1] - synth.field_linear(tgt)) / 10.0), np.broadcast_to(layer_b[:, None], got[1].shape))
+    with pytest.raises(ValueError):
+        api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV"], layers=[5])
+
+
+@pytest.mark.gpu
+def test_fluid_solid_fix_equals_the_reference_statements():
+    from multimesh_amd import api
+
+    rng = np.random.default_rng(3)
+    E, C, P = 500, 3, 27
+    values = rng.uniform(1.0, 2.0, size=(E, C, P))
+    new_values = rng.uniform(5.0, 6.0, size=(E, C, P))          # what the target mesh held before (interpolator.py:690)
+    solid_elements = rng.random(E) > 0.3
+    values[rng.choice(E, 60, replace=False), 1, rng.integers(0, P, 60)] = 0.0     # zero VSV here and there
+    parameters = ["RHO", "VSV", "VPV"]
+    got = api.fix_fluid_solid(values, new_values, solid_elements, parameters)
+    # reference interpolator.py:829-841, verbatim on copies
+    want = values.copy()
+    want[~solid_elements] = new_values[~solid_elements]
+    vs_index = parameters.index("VSV")
+    zero_vs = np.where(want[:, vs_index, :] == 0.0)
+    for _i, elem in enumerate(np.unique(zero_vs[0])):
+        if solid_elements[elem]:
+            want[elem, :, :] = new_values[elem, :, :]
+    assert np.array_equal(got, want)
