@@ -33,6 +33,8 @@
 // HBM-bound by the roofline accounting (568 B/target when the first candidate is accepted:
 // 24 point + 8k candidates + 64 connectivity row + 192 corner coordinates + 128 out), though
 // the lane spends most of its time in the dependent Newton chain; corner gathers hit L2.
+#include <cstring>
+
 #include "mm_common.h"
 
 namespace {
@@ -361,6 +363,25 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// Diagnostic builds only (make EXTRA=-DMM_LOCATE_STAMPS): where a wave of locate_pass_kernel spends its cycles
+// (s_memtime ticks per phase, summed per workgroup slot; tools/locate_stamps.py prints the shares).
+#ifdef MM_LOCATE_STAMPS
+constexpr int kLocStampSlots = 4096;
+__device__ unsigned long long g_loc_stamps[kLocStampSlots * 8];
+#define MM_LSTAMP(n)                                                                   \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
+        stamp_sum[n] += now_ - stamp_last;                                             \
+        stamp_last = now_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#else
+#define MM_LSTAMP(n) do { } while (0)
+#endif
+
 template <bool EXODUS, typename IDX>
 __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints,
                                                                  const IDX *__restrict__ nn,
@@ -393,6 +414,11 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
     const i64 nwaves = (i64)((gridDim.x - xcd + nx - 1) / nx) * (kPassBlock / 64);   // waves of this XCD
     const i64 wave = (i64)(blockIdx.x / nx) * (kPassBlock / 64) + (threadIdx.x >> 6);
     i64 next = (b_lo + wave) * 64;  // first target of this wave's next fresh batch
+#ifdef MM_LOCATE_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (;;) {
         // A wave always runs DENSE: as soon as 64 entries are waiting in a queue it solves those (most
         // recent first: their point, candidate row and mesh lines are still in cache), the slower tiers
@@ -458,8 +484,13 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         int outcome = 0;
         Corners c;
         double wt[8];
+        MM_LSTAMP(0);   // round selection, queue reads
         if (active) {
             const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+#ifdef MM_LOCATE_STAMPS
+            asm volatile("" ::"v"(px), "v"(py), "v"(pz));
+            MM_LSTAMP(1);   // the target's coordinates here
+#endif
             // skip-scan: next candidate whose x/y corner box (widened by 5 %) contains the point (a lane
             // that works ahead looks at its one candidate only: outside the box = rejected)
             bool have = false;
@@ -488,11 +519,19 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
                 if (lgG > 0) break;  // working ahead: this one candidate only
             }
+#ifdef MM_LOCATE_STAMPS
+            asm volatile("" ::"v"(c.x[0]), "v"(c.z[7]));
+            MM_LSTAMP(2);   // candidate row, connectivity row, corner coordinates, box test
+#endif
             if (j >= k) {
                 outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
             } else if (have) {
                 double xi[3];
                 const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap);
+#ifdef MM_LOCATE_STAMPS
+                asm volatile("" ::"v"(xi[0]), "v"(xi[2]));
+                MM_LSTAMP(3);   // Newton
+#endif
                 if (converged && in_hull(xi) && max_abs3(xi) < (1 + 0.025)) {
                     weights_hex8(xi, wt);
                     outcome = 1;
@@ -501,6 +540,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
             }
         }
+        MM_LSTAMP(4);   // weights
         // the first lane of a target's group (the whole group when nobody works ahead) whose outcome is
         // not a rejection decides; if all rejected, the group's first lane moves on behind the group
         bool requeue = false, slower = false;
@@ -526,6 +566,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 }
             }
         }
+        MM_LSTAMP(5);   // emit: gathers of the field, stores
         // unresolved targets go to the wave's own queues (slot = ballot prefix, no atomics); fewer than
         // 64 were waiting in a queue and at most 64 are added, so kWaveQueue = 128 entries suffice
         const unsigned long long vote = __ballot(requeue);
@@ -542,7 +583,15 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             else held2 += __popcll(svote);
         }
         wave_fence();
+        MM_LSTAMP(6);   // queue appends
     }
+#ifdef MM_LOCATE_STAMPS
+    if (lane == 0) {
+        unsigned long long *slot = g_loc_stamps + (size_t)((blockIdx.x * (kPassBlock / 64) + (threadIdx.x >> 6)) & (kLocStampSlots - 1)) * 8;
+        for (int q = 0; q < 7; ++q) slot[q] += stamp_sum[q];
+        slot[7] += 1ull;
+    }
+#endif
 }
 
 }  // namespace
@@ -653,6 +702,24 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
     return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
                                     d_nfailed, zero_failed, nullptr);
 }
+
+#ifdef MM_LOCATE_STAMPS
+extern "C" int mm_debug_locate_stamps(unsigned long long *out16, int reset)
+{
+    static unsigned long long host[kLocStampSlots * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_loc_stamps), sizeof(host)) != hipSuccess) return -1;
+    for (int q = 0; q < 16; ++q) out16[q] = 0;
+    for (int b = 0; b < kLocStampSlots; ++b) {
+        for (int q = 0; q < 7; ++q) out16[q] += host[b * 8 + q];
+        out16[15] += host[b * 8 + 7];
+    }
+    if (reset) {
+        memset(host, 0, sizeof(host));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_loc_stamps), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int64_t mm_locate_hex8(mm_context *ctx, int64_t k, int64_t npoints, const int64_t *nn_d,
                                   const int64_t *conn_d, int64_t nelem, int conn_is_exodus,
