@@ -1,16 +1,17 @@
 """profiles/*_pmc_traffic.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE).
 
 usage: make_traffic_profile.py <dir with FETCH_SIZE csv> <dir with WRITE_SIZE csv> <out.json>
-Counters are summed per dispatch; per kernel the value kept is the mean over dispatches, except for
-the locate pass kernel where the largest dispatch (the pass over all targets) is taken.
+Counters are summed per dispatch; per kernel the value kept is the MEDIAN over its dispatches (the bench also
+runs the pipeline once with the operator written out and twice from host arrays: the median is a plain step).
 hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: the gfx950 correction of
 MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide coalesced read stream) -- an upper estimate for
 kernels whose reads are not 16-byte-per-lane streams; raw_bytes_per_launch = (FETCH + WRITE) * 1024.
 """
 import csv, glob, json, sys, collections
 
-KERNELS = {"knn_cell": "knn_strip_kernel", "centroid": "centroid_", "locate_pass0": "locate_pass_kernel",
-           "gather": "gather8_kernel", "locate_long_pass": "Li50E"}
+KERNELS = {"knn_cell": "knn_lane_kernel", "knn_strip_kernel": "knn_strip_kernel", "centroid": "centroid_",
+           "locate_pass0": "locate_pass_kernel", "gather": "gather8_kernel", "cell_scatter": "cell_scatter_kernel",
+           "target_scatter": "target_scatter_kernel"}
 
 
 def per_dispatch(d, counter):
@@ -26,11 +27,11 @@ fetch, write = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2]
 res = {"_note": __doc__.strip().split("\n\n", 1)[1].replace("\n", " ")}
 for stage, pat in KERNELS.items():
     def pick(table):
-        vals = [v for name, disp in table.items() if pat in name and (stage != "locate_pass0" or "Li50E" not in name)
-                for v in disp.values()]
+        vals = [v for name, disp in table.items() if pat in name for v in disp.values()]
         if not vals:
             return None
-        return max(vals) if stage == "locate_pass0" else sum(vals) / len(vals)
+        vals.sort()
+        return vals[len(vals) // 2]
     f, w = pick(fetch), pick(write)
     if f is None or w is None:
         continue
