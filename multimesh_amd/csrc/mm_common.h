@@ -48,6 +48,7 @@ enum mm_buffer_slot {
     MM_BUF_SORTED_XYZ,
     MM_BUF_NN_FULL,
     MM_BUF_BOX_PARTIAL,
+    MM_BUF_TSORTED,                       // targets in cell order {x, y, z, index} (kept for the locate stage)
     MM_BUF_H_NODES,                       // device copies of host arrays (mm_interpolate_hex8_host)
     MM_BUF_H_CONN,
     MM_BUF_H_POINTS,
@@ -113,7 +114,7 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
                           const i64 *conn, i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes,
                           double *w, const double *pts, i64 *d_nfailed, int zero_failed,
                           const double *fields, i64 nnodes, i64 ncomp, double *out,
-                          const mm_lazy_lists *lazy);
+                          const mm_lazy_lists *lazy, const double *tsorted = nullptr);
 // full-length int32 lists for a device-side list of targets (generic kernel, rows idx[i*k ...])
 int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,
                            int *idx_d, const int *list, const int *list_count);

@@ -348,11 +348,12 @@ __device__ __forceinline__ void knn_query_one(const GridParams &g, i64 nsrc, con
                                               const double *__restrict__ sorted_xyz,
                                               const double *__restrict__ pts,
                                               int ndim, int kout, IDX *__restrict__ idx_out,
-                                              double *__restrict__ dist_out, i64 i)
+                                              double *__restrict__ dist_out, i64 i, int pstride)
 {
-    const double px = pts[i * ndim];
-    const double py = ndim > 1 ? pts[i * ndim + 1] : 0.0;
-    const double pz = ndim > 2 ? pts[i * ndim + 2] : 0.0;
+    // pstride: doubles per point (ndim for the caller's array, kRec for cell-sorted target records)
+    const double px = pts[i * pstride];
+    const double py = ndim > 1 ? pts[i * pstride + 1] : 0.0;
+    const double pz = ndim > 2 ? pts[i * pstride + 2] : 0.0;
     const int cx = cell_coord(px, g.lox, g.ihx, g.nx);
     const int cy = cell_coord(py, g.loy, g.ihy, g.ny);
     const int cz = cell_coord(pz, g.loz, g.ihz, g.nz);
@@ -466,14 +467,14 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
                                                            int kout, IDX *__restrict__ idx_out,
                                                            double *__restrict__ dist_out,
                                                            const int *__restrict__ list,
-                                                           const int *__restrict__ list_count)
+                                                           const int *__restrict__ list_count, int pstride)
 {
     // list != null: only the queued targets (stragglers of the fast kernel), grid-stride
     const i64 total = list ? (i64)*list_count : npts;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
         knn_query_one<K, IDX>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
-                         list ? (i64)list[q] : q);
+                         list ? (i64)list[q] : q, pstride);
 }
 
 // List mode over the density levels of a graded cloud: every listed target is searched in the first
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv,
                 }
             if (block <= 27 * keep_max) break;
         }
-        knn_query_one<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], pts, ndim, kout, idx_out, dist_out, i);
+        knn_query_one<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], pts, ndim, kout, idx_out, dist_out, i, ndim);
     }
 }
 
@@ -1645,8 +1646,12 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                                                             const double *__restrict__ tsorted, IDX *__restrict__ idx_out,
                                                             double *__restrict__ dist_out, int *__restrict__ fb_list,
                                                             int *__restrict__ fb_count, const int2 *__restrict__ items,
-                                                            const int *__restrict__ item_total, int Z, int per_item)
+                                                            const int *__restrict__ item_total, int Z, int per_item,
+                                                            int sorted_rows)
 {
+    // sorted_rows: a target's row goes to its position in the cell-sorted order (the fused pipeline's locate
+    // stage then walks the targets in that order: rows and coordinates stream, neighbours share elements) and
+    // hand-overs are queued by that position; otherwise to the target's own index.
     constexpr int L = K + 2;        // keys kept per target
     constexpr int NE = K + 1;       // of which the first K + 1 get exact distances
     static_assert(K >= 1 && NE <= 32, "rank masks are 32 bits");
@@ -1766,7 +1771,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             int base = 0;
             if (lane == 0) base = atomicAdd(fb_count, tn);
             base = __shfl(base, 0);
-            for (int q = lane; q < tn; q += kWave) fb_list[base + q] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+            for (int q = lane; q < tn; q += kWave)
+                fb_list[base + q] = sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
             continue;
         }
         // ---- stage, step 1: every entry's position in the sorted array (the cells' owners know them) ...
@@ -1816,7 +1822,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         for (int r0 = 0; r0 < tn; r0 += kWave) {
             const bool valid = r0 + lane < tn;
             const double px = npx, py = npy, pz = npz;
-            const i64 i = (i64)record_id(npw);
+            const i64 i = sorted_rows ? (i64)(t0 + r0 + lane) : (i64)record_id(npw);
             if (r0 + kWave < tn) {
                 // the next round's targets, in flight during this round
                 const int q = r0 + kWave + lane;
@@ -2046,6 +2052,7 @@ __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__re
 constexpr int kLaneMaxK = 20;
 struct LaneWork {
     int Z;
+    int sorted_rows;     // rows and hand-overs by position in the cell-sorted order
     i64 nstrips_total;   // columns x strips per column
     i64 max_items;       // upper bound on the work items: strips + targets / (64 * kLaneRounds)
     int *nparts;         // [nstrips_total + 1]
@@ -2056,13 +2063,14 @@ struct LaneWork {
 
 template <int K, typename IDX>
 void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                    int kout, IDX *idx, double *dist, const int *list, const int *list_count)
+                    int kout, IDX *idx, double *dist, const int *list, const int *list_count, int pstride = 0)
 {
+    if (pstride == 0) pstride = ix->ndim;
     i64 grid = (npts + kBlock - 1) / kBlock;
     if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
     hipLaunchKernelGGL((knn_query_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
                        ix->cell_start, ix->sorted_xyz, pts, npts, ix->ndim, kout, idx, dist, list,
-                       list_count);
+                       list_count, pstride);
 }
 
 // Strips of a level that hold targets, as workgroup ids of knn_strip_kernel (nsplit parts each).
@@ -2131,7 +2139,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
         hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
                            ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count,
-                           lane->items, lane->item_start + lane->nstrips_total, lane->Z, per_item);
+                           lane->items, lane->item_start + lane->nstrips_total, lane->Z, per_item, lane->sorted_rows);
         if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
         return;
     }
@@ -2423,10 +2431,14 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     return MM_OK;
 }
 
+// tsorted_out (nullable): the caller can take the rows in the cell-sorted order of the targets; on return
+// *tsorted_out = the sorted target records {x, y, z, index} (context buffer, valid until the next query) when the
+// rows were written in that order, null when they are in the targets' own order (paths without the lane kernel).
 template <typename IDX>
 static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, IDX *idx_d,
-                           double *dist_d)
+                           double *dist_d, const double **tsorted_out)
 {
+    if (tsorted_out) *tsorted_out = nullptr;
     if (npts == 0 || k == 0) return MM_OK;
     MM_REQUIRE(npts < (i64)0x7fffffff, "too many targets for one query");
     const GridParams g = params_of(ix);
@@ -2484,6 +2496,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     LaneWork lane_work;
     bool use_lane = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK && npts >= 2 * ix->ncells;
     if (force_kernel) use_lane = strcmp(force_kernel, "lane") == 0 && !ix->fine && ix->dims[2] >= 2 && k <= kLaneMaxK;
+    const bool sorted_rows = use_lane && tsorted_out != nullptr && !getenv("MM_KNN_UNSORTED_ROWS");
+    lane_work.sorted_rows = sorted_rows ? 1 : 0;
     if (use_lane) {
         static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
         lane_work.Z = force_z >= 1 && force_z <= kLaneZMax ? force_z : kLaneZ;
@@ -2529,7 +2543,15 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         int *down_count = (int *)mm_scratch_take(ctx, 256);
         int *strip_count = down_count ? down_count + 1 : nullptr;
         unsigned *strip_list = level > 0 ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
-        double *tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
+        double *tsorted = nullptr;
+        if (sorted_rows) {
+            // (outlives this call's scratch: the locate stage reads it)
+            int brc = mm_buffer_get(ctx, MM_BUF_TSORTED, (size_t)npts * kRec * sizeof(double), (void **)&tsorted);
+            if (brc != MM_OK) return brc;
+            *tsorted_out = tsorted;
+        } else {
+            tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
+        }
         if (!tsorted || !cell_of || !counts || !start || !tile_sums || !down_count || (l->fine && !down_list) ||
             (level > 0 && !strip_list)) {
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
@@ -2585,6 +2607,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, IDX>), dim3((unsigned)ggrid), dim3(kBlock), 0, ctx->stream, lv, \
                                ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax,     \
                                npts);                                                                       \
+        else if (sorted_rows)                                                                                        \
+            launch_generic<KK, IDX>(ctx, ix, g, *tsorted_out, npts, kout, idx_d, dist_d, fb_list, fb_count, kRec);    \
         else                                                                                                         \
             launch_generic<KK, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, fb_list, fb_count);                \
     } while (0)
@@ -2641,8 +2665,15 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
                       double *dist_d, bool idx_is_int32)
 {
-    if (idx_is_int32) return knn_query_typed<int>(ctx, ix, pts_d, npts, k, (int *)idx_d, dist_d);
-    return knn_query_typed<i64>(ctx, ix, pts_d, npts, k, (i64 *)idx_d, dist_d);
+    if (idx_is_int32) return knn_query_typed<int>(ctx, ix, pts_d, npts, k, (int *)idx_d, dist_d, nullptr);
+    return knn_query_typed<i64>(ctx, ix, pts_d, npts, k, (i64 *)idx_d, dist_d, nullptr);
+}
+
+// int32 rows, in the cell-sorted order of the targets when the lane kernel serves the query (see knn_query_typed)
+int mm_knn_query_sorted_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, int *idx_d,
+                             const double **tsorted_out)
+{
+    return knn_query_typed<int>(ctx, ix, pts_d, npts, k, idx_d, nullptr, tsorted_out);
 }
 
 extern "C" int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, int64_t ndim, mm_knn_index **out)

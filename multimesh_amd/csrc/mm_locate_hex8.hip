@@ -382,7 +382,11 @@ __device__ unsigned long long g_loc_stamps[kLocStampSlots * 8];
 #define MM_LSTAMP(n) do { } while (0)
 #endif
 
-template <bool EXODUS, typename IDX>
+// SORTED: the targets come as cell-sorted records {x, y, z, index} (the kNN stage's) and the candidate rows in
+// the same order: a wave's 64 targets are 8 neighbouring grid cells -- coordinates and rows stream, and the
+// lanes share their candidate elements' connectivity rows and nodes.  i is then the position in that order
+// (points, rows, queues), the target's own index (outputs, reference-order list) comes out of its record.
+template <bool EXODUS, typename IDX, bool SORTED>
 __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints,
                                                                  const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
@@ -485,8 +489,21 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         Corners c;
         double wt[8];
         MM_LSTAMP(0);   // round selection, queue reads
+        i64 tid = i;   // the target's own index
         if (active) {
-            const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+            double px, py, pz;
+            if (SORTED) {
+                const double2 *r2 = reinterpret_cast<const double2 *>(pts + i * 4);
+                const double2 xy = r2[0], zw = r2[1];
+                px = xy.x;
+                py = xy.y;
+                pz = zw.x;
+                tid = (i64)(int)__double_as_longlong(zw.y);
+            } else {
+                px = pts[i * 3 + 0];
+                py = pts[i * 3 + 1];
+                pz = pts[i * 3 + 2];
+            }
 #ifdef MM_LOCATE_STAMPS
             asm volatile("" ::"v"(px), "v"(py), "v"(pz));
             MM_LSTAMP(1);   // the target's coordinates here
@@ -553,16 +570,16 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             const int first = mine ? __ffsll((long long)mine) - 1 : G;
             const int g = lane - group_base;
             if (active && g == first) {
-                if (outcome == 1) emit_row(em, i, c.id, wt);
+                if (outcome == 1) emit_row(em, tid, c.id, wt);
                 else if (outcome == 2) slower = true;
-                else slow_list[atomicAdd(slow_count, 1)] = (int)i;
+                else slow_list[atomicAdd(slow_count, 1)] = (int)tid;
             } else if (active && first == G && g == 0) {
                 // every candidate of the group rejected (j is this lane's, the group's first)
                 if (j + G < k) {
                     requeue = true;
                     requeue_j = j + G;
                 } else {
-                    slow_list[atomicAdd(slow_count, 1)] = (int)i;
+                    slow_list[atomicAdd(slow_count, 1)] = (int)tid;
                 }
             }
         }
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
 template <typename IDX>
 static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *nn, const i64 *conn, i64 nelem,
                                int conn_is_exodus, const Emit &em, const double *nodes, const double *pts,
-                               i64 *d_nfailed, int zero_failed, const mm_lazy_lists *lazy)
+                               i64 *d_nfailed, int zero_failed, const mm_lazy_lists *lazy, const double *tsorted)
 {
     MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
     if (npoints == 0 || k == 0) return MM_OK;
@@ -623,7 +640,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     i64 resident = 0;
     {
         int per_cu = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX>, kPassBlock, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, false>, kPassBlock, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         if (e != hipSuccess || per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
@@ -639,12 +656,20 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
     {
         dim3 g_((unsigned)grid), b_(block);
-        if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, slow, slow_count);
+        // (tsorted: rows nn[] and the records are in the kNN stage's cell-sorted order; the reference-order kernel
+        // below works on the targets' own indices either way)
+        if (tsorted && conn_is_exodus)
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, true>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                               em, nodes, tsorted, slow, slow_count);
+        else if (tsorted)
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, true>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                               em, nodes, tsorted, slow, slow_count);
+        else if (conn_is_exodus)
+            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, false>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                               em, nodes, pts, slow, slow_count);
         else
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em,
-                               nodes, pts, slow, slow_count);
+            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, false>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
+                               em, nodes, pts, slow, slow_count);
     }
     mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     // out of candidates without an acceptance: reference-order kernel
@@ -687,7 +712,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
 int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, bool nn_is_int32, const i64 *conn,
                           i64 nelem, int conn_is_exodus, i64 *enc, const double *nodes, double *w, const double *pts,
                           i64 *d_nfailed, int zero_failed, const double *fields, i64 nnodes, i64 ncomp, double *out,
-                          const mm_lazy_lists *lazy)
+                          const mm_lazy_lists *lazy, const double *tsorted)
 {
     Emit em;
     em.enc = (enc && w) ? enc : nullptr;
@@ -698,9 +723,9 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
     em.out = (fields && out && ncomp > 0) ? out : nullptr;
     if (nn_is_int32)
         return launch_locate_typed<int>(ctx, k, npoints, (const int *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
-                                        d_nfailed, zero_failed, lazy);
+                                        d_nfailed, zero_failed, lazy, tsorted);
     return launch_locate_typed<i64>(ctx, k, npoints, (const i64 *)nn, conn, nelem, conn_is_exodus, em, nodes, pts,
-                                    d_nfailed, zero_failed, nullptr);
+                                    d_nfailed, zero_failed, nullptr, nullptr);
 }
 
 #ifdef MM_LOCATE_STAMPS

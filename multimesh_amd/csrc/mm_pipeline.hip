@@ -10,6 +10,8 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
                       bool use_context_buffers, const double *box_partial_d, int box_nblocks);
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
                       double *dist_d, bool idx_is_int32);
+int mm_knn_query_sorted_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, int *idx_d,
+                             const double **tsorted_out);
 void mm_clear_status(void);
 
 // candidates delivered up front when the lists are evaluated lazily (99.9 % of mesh-node targets are
@@ -85,6 +87,7 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     // full k only on demand inside the locate stage
     const int64_t kq = (ctx->lazy_lists && k > kLazyK) ? kLazyK : k;
     int *nn_full = nullptr;
+    const double *tsorted = nullptr;
     mm_lazy_lists lazy;
     rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
     if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_BOX_PARTIAL, (size_t)kBoxBlocks * 6 * sizeof(double), (void **)&box_partial);
@@ -125,7 +128,11 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
 
     if (feed && (rc = feed_upload(ctx, feed, 2, 2, 1)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
-    rc = mm_knn_query_impl(ctx, index, points_d, npoints, kq, nn, nullptr, true);
+    // (the candidate rows come back in the cell-sorted order of the targets whenever the lane kernel serves the
+    // query: the locate stage then walks the targets in that order, tsorted = their records)
+    // (only with lazily evaluated lists: the reference-order kernel then reads the FULL lists, which are rows
+    // by the targets' own indices; with eager lists it reads these rows and needs them in that order)
+    rc = mm_knn_query_sorted_impl(ctx, index, points_d, npoints, kq, nn, kq < k ? &tsorted : nullptr);
     mm_stage_end(ctx, MM_STAGE_KNN_QUERY);
     if (rc != MM_OK) { result = rc; goto done; }
 
@@ -139,7 +146,7 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     rc = mm_launch_locate_hex8(ctx, kq, npoints, nn, /*int32=*/true, (const i64 *)conn_d, nelem, /*exodus=*/1, enc,
                                nodes_d, w, points_d, ctx->d_counters, /*zero_failed=*/1,
                                fuse_gather ? fields_d : nullptr, nnodes, ncomp, out_d,
-                               kq < k ? &lazy : nullptr);
+                               kq < k ? &lazy : nullptr, tsorted);
     mm_stage_end(ctx, MM_STAGE_LOCATE);
     if (rc != MM_OK) { result = rc; goto done; }
     if (want_values && !fuse_gather) {
