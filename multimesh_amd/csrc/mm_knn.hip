@@ -1620,13 +1620,25 @@ __global__ __launch_bounds__(kBlock) void lane_items_count_kernel(GridParams g, 
     nparts[t] = (tn + per_item - 1) / per_item;
 }
 
+// Item q of the list (strips in spatial order) is stored at slot 8 m + x, x = the eighth of the list it lies in,
+// m = its place inside that eighth: workgroup b of the lane kernel simply takes slot b -- workgroups are dealt
+// round-robin over the 8 XCDs, so XCD x walks the x-th eighth of the list, a contiguous piece of space (its L2
+// sees each source about once), and the workgroup's first load depends on nothing but its own index.  Slots
+// without an item stay at -1 (the array is pre-set).
 __global__ __launch_bounds__(kBlock) void lane_items_fill_kernel(const int *__restrict__ item_start, i64 nstrips_total,
                                                                  int2 *__restrict__ items)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nstrips_total) return;
     const int a = item_start[t], b = item_start[t + 1];
-    for (int q = a; q < b; ++q) items[q] = make_int2((int)t, q - a);
+    const i64 total = item_start[nstrips_total];
+    for (int q = a; q < b; ++q) {
+        int x = (int)(((i64)q * 8) / total);
+        while (x > 0 && (i64)q < ((total * x) >> 3)) --x;
+        while (x < 7 && (i64)q >= ((total * (x + 1)) >> 3)) ++x;
+        const i64 m = (i64)q - ((total * x) >> 3);
+        items[8 * m + x] = make_int2((int)t, q - a);
+    }
 }
 
 // neg_inf: -inf in a register the compiler cannot see through -- med3(-inf, c, d0) = min(c, d0) as ONE
@@ -1646,8 +1658,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                                                             const double *__restrict__ tsorted, IDX *__restrict__ idx_out,
                                                             double *__restrict__ dist_out, int *__restrict__ fb_list,
                                                             int *__restrict__ fb_count, const int2 *__restrict__ items,
-                                                            const int *__restrict__ item_total, int Z, int per_item,
-                                                            int sorted_rows)
+                                                            int nslots, int Z, int per_item, int sorted_rows)
 {
     // sorted_rows: a target's row goes to its position in the cell-sorted order (the fused pipeline's locate
     // stage then walks the targets in that order: rows and coordinates stream, neighbours share elements) and
@@ -1667,16 +1678,14 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    const int total_items = *item_total;
-    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-    const int first = (int)(((i64)total_items * xcd) >> 3), last = (int)(((i64)total_items * (xcd + 1)) >> 3);
     const int nstrips = (g.nz + Z - 1) / Z;
     const float4 far_entry = make_float4(kLaneFar, kLaneFar, kLaneFar, __int_as_float(-1));
     bool staged_before = false;
-    for (int it = first + (int)(blockIdx.x >> 3); it < last; it += per_xcd) {
+    for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {   // (one slot per workgroup by default)
+        const int2 item = items[slot];
+        if (item.x < 0) continue;
         if (staged_before) wave_sync();   // the previous item's tile and rows are done with
         staged_before = true;
-        const int2 item = items[it];
 #ifdef MM_LANE_STAMPS
         asm volatile("" ::"s"(item.x));
 #endif
@@ -1782,29 +1791,31 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         if (lane < kLanePad) tile[total + lane] = far_entry;   // a window read may run past the tile's end
         wave_sync();
         MM_STAMP(2);   // positions written
-        // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, four records in flight per
-        // lane, ONE global round trip for the whole tile (copying cell by cell was a chain of them)
-        for (int e0 = 0; e0 < total; e0 += 4 * kWave) {
-            int pos[4];
-            double2 xy[4], zw[4];
+        // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, six records in flight per
+        // lane (copying cell by cell was a chain of round trips)
+        constexpr int kTrips = 6;   // ~10 trips per tile: two groups, i.e. two global round trips (three with 4)
+        for (int e0 = 0; e0 < total; e0 += kTrips * kWave) {
+            int pos[kTrips];
+            double2 xy[kTrips];
+            double zc[kTrips];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kTrips; ++u) {
                 const int e = e0 + u * kWave + lane;
                 pos[u] = e < total ? reinterpret_cast<const int *>(tile + e)[3] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)max(pos[u], 0) * kRec);
-                xy[u] = r2[0];
-                zw[u] = r2[1];
+            for (int u = 0; u < kTrips; ++u) {
+                const double *rec = sorted_xyz + (i64)max(pos[u], 0) * kRec;
+                xy[u] = *reinterpret_cast<const double2 *>(rec);
+                zc[u] = rec[2];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < kTrips; ++u)
                 if (pos[u] >= 0) {
                     // non-finite or absurdly far sources become far-away entries (never NaN in a key)
                     const float fx = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
                     const float fy = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
-                    const float fz = fminf(fmaxf((float)(zw[u].x - oz), -kLaneFar), kLaneFar);
+                    const float fz = fminf(fmaxf((float)(zc[u] - oz), -kLaneFar), kLaneFar);
                     float *dst = reinterpret_cast<float *>(tile + e0 + u * kWave + lane);
                     *reinterpret_cast<float2 *>(dst) = make_float2(fx, fy);
                     dst[2] = fz;
@@ -2130,6 +2141,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         hipLaunchKernelGGL(lane_items_count_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, g, tstart, lane->Z, per_item,
                            lane->nparts, lane->nstrips_total);
         (void)mm_exclusive_scan_int(ctx, lane->nparts, lane->nstrips_total, lane->item_start, lane->tile_sums);
+        (void)hipMemsetAsync(lane->items, 0xff, (size_t)lane->max_items * sizeof(int2), ctx->stream);   // -1: no item
         hipLaunchKernelGGL(lane_items_fill_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, lane->item_start,
                            lane->nstrips_total, lane->items);
         static const i64 force_grid = getenv("MM_KNN_LANE_GRID") ? atoll(getenv("MM_KNN_LANE_GRID")) : 0;
@@ -2139,7 +2151,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
         hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
                            ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count,
-                           lane->items, lane->item_start + lane->nstrips_total, lane->Z, per_item, lane->sorted_rows);
+                           lane->items, (int)lane->max_items, lane->Z, per_item, lane->sorted_rows);
         if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
         return;
     }
@@ -2504,7 +2516,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         if (lane_work.Z > ix->dims[2]) lane_work.Z = ix->dims[2];
         const i64 nstrips = (ix->dims[2] + lane_work.Z - 1) / lane_work.Z;
         lane_work.nstrips_total = (i64)ix->dims[0] * ix->dims[1] * nstrips;
-        lane_work.max_items = lane_work.nstrips_total + npts / (kWave * kLaneRounds) + 8;
+        // (slots: 8 per row of the permuted list, so up to 7 more than items; a multiple of 8 = the grid)
+        lane_work.max_items = (lane_work.nstrips_total + npts / (kWave * kLaneRounds) + 16 + 7) / 8 * 8;
         need += 2 * mm_round256((size_t)(lane_work.nstrips_total + 1) * sizeof(int)) +
                 mm_round256((size_t)((lane_work.nstrips_total + kScanTile) / kScanTile) * sizeof(int)) +
                 mm_round256((size_t)lane_work.max_items * sizeof(int2)) + 1024;
