@@ -112,8 +112,10 @@ struct Gll {
             }
             // Tensor-product (sum-factorised) evaluation of the map and its Jacobian, in exactly the
             // oracle's order of partial sums (mmo_gll_inverse_transform): innermost over i with l0 /
-            // dl0, then over j, then over k -- 2.1 k instead of 4 k fp64 operations per step at order 4
-            // and a third of the live registers.
+            // dl0, then over j, then over k -- and every partial sum accumulated with ONE fused multiply-add
+            // (this path's arithmetic is our own definition, the oracle uses fma() at the same places):
+            // ~1.2 k fp64 instructions per step at order 4 instead of 2.1 k, a third of the live registers
+            // of the plain triple sum.
             if (DIM == 3) {
 #pragma unroll
                 for (int k = 0; k < n; ++k) {
@@ -130,23 +132,23 @@ struct Gll {
 #pragma unroll
                             for (int a = 0; a < 3; ++a) {
                                 const double Xa = X[a];
-                                a0[a] = a0[a] + l[0][i] * Xa;
-                                a1[a] = a1[a] + dl[0][i] * Xa;
+                                a0[a] = __builtin_fma(l[0][i], Xa, a0[a]);
+                                a1[a] = __builtin_fma(dl[0][i], Xa, a1[a]);
                             }
                         }
 #pragma unroll
                         for (int a = 0; a < 3; ++a) {
-                            b00[a] = b00[a] + l[1][j] * a0[a];
-                            b01[a] = b01[a] + dl[1][j] * a0[a];
-                            b10[a] = b10[a] + l[1][j] * a1[a];
+                            b00[a] = __builtin_fma(l[1][j], a0[a], b00[a]);
+                            b01[a] = __builtin_fma(dl[1][j], a0[a], b01[a]);
+                            b10[a] = __builtin_fma(l[1][j], a1[a], b10[a]);
                         }
                     }
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        x[a] = x[a] + l[DIM - 1][k] * b00[a];
-                        J[a][0] = J[a][0] + l[DIM - 1][k] * b10[a];
-                        J[a][1] = J[a][1] + l[DIM - 1][k] * b01[a];
-                        J[a][DIM - 1] = J[a][DIM - 1] + dl[DIM - 1][k] * b00[a];
+                        x[a] = __builtin_fma(l[DIM - 1][k], b00[a], x[a]);
+                        J[a][0] = __builtin_fma(l[DIM - 1][k], b10[a], J[a][0]);
+                        J[a][1] = __builtin_fma(l[DIM - 1][k], b01[a], J[a][1]);
+                        J[a][DIM - 1] = __builtin_fma(dl[DIM - 1][k], b00[a], J[a][DIM - 1]);
                     }
                 }
             } else {
@@ -159,15 +161,15 @@ struct Gll {
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
                             const double Xa = X[a];
-                            a0[a] = a0[a] + l[0][i] * Xa;
-                            a1[a] = a1[a] + dl[0][i] * Xa;
+                            a0[a] = __builtin_fma(l[0][i], Xa, a0[a]);
+                            a1[a] = __builtin_fma(dl[0][i], Xa, a1[a]);
                         }
                     }
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        x[a] = x[a] + l[1][j] * a0[a];
-                        J[a][0] = J[a][0] + l[1][j] * a1[a];
-                        J[a][1] = J[a][1] + dl[1][j] * a0[a];
+                        x[a] = __builtin_fma(l[1][j], a0[a], x[a]);
+                        J[a][0] = __builtin_fma(l[1][j], a1[a], J[a][0]);
+                        J[a][1] = __builtin_fma(dl[1][j], a0[a], J[a][1]);
                     }
                 }
             }

@@ -453,7 +453,9 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
         double x[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         /* Tensor-product (sum-factorised) evaluation of the map and its Jacobian; the order of the
          * partial sums below IS the definition of this path's arithmetic (the HIP kernel follows it
-         * operation for operation): innermost over i with l0 / dl0, then over j, then over k. */
+         * operation for operation): innermost over i with l0 / dl0, then over j, then over k, every partial
+         * sum accumulated with one fused multiply-add (C99 fma(): correctly rounded, so identical to
+         * the GPU's v_fma_f64). */
         if (dim == 3) {
             for (int k = 0; k < n; ++k) {
                 double b00[3] = {0, 0, 0}, b01[3] = {0, 0, 0}, b10[3] = {0, 0, 0};
@@ -462,21 +464,21 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
                     for (int i = 0; i < n; ++i) {
                         const double *X = ctrl + 3 * (i + n * (j + n * k));
                         for (int a = 0; a < 3; ++a) {
-                            a0[a] = a0[a] + l[0][i] * X[a];
-                            a1[a] = a1[a] + dl[0][i] * X[a];
+                            a0[a] = fma(l[0][i], X[a], a0[a]);
+                            a1[a] = fma(dl[0][i], X[a], a1[a]);
                         }
                     }
                     for (int a = 0; a < 3; ++a) {
-                        b00[a] = b00[a] + l[1][j] * a0[a];
-                        b01[a] = b01[a] + dl[1][j] * a0[a];
-                        b10[a] = b10[a] + l[1][j] * a1[a];
+                        b00[a] = fma(l[1][j], a0[a], b00[a]);
+                        b01[a] = fma(dl[1][j], a0[a], b01[a]);
+                        b10[a] = fma(l[1][j], a1[a], b10[a]);
                     }
                 }
                 for (int a = 0; a < 3; ++a) {
-                    x[a] = x[a] + l[2][k] * b00[a];
-                    J[a][0] = J[a][0] + l[2][k] * b10[a];
-                    J[a][1] = J[a][1] + l[2][k] * b01[a];
-                    J[a][2] = J[a][2] + dl[2][k] * b00[a];
+                    x[a] = fma(l[2][k], b00[a], x[a]);
+                    J[a][0] = fma(l[2][k], b10[a], J[a][0]);
+                    J[a][1] = fma(l[2][k], b01[a], J[a][1]);
+                    J[a][2] = fma(dl[2][k], b00[a], J[a][2]);
                 }
             }
         } else {
@@ -485,14 +487,14 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
                 for (int i = 0; i < n; ++i) {
                     const double *X = ctrl + 2 * (i + n * j);
                     for (int a = 0; a < 2; ++a) {
-                        a0[a] = a0[a] + l[0][i] * X[a];
-                        a1[a] = a1[a] + dl[0][i] * X[a];
+                        a0[a] = fma(l[0][i], X[a], a0[a]);
+                        a1[a] = fma(dl[0][i], X[a], a1[a]);
                     }
                 }
                 for (int a = 0; a < 2; ++a) {
-                    x[a] = x[a] + l[1][j] * a0[a];
-                    J[a][0] = J[a][0] + l[1][j] * a1[a];
-                    J[a][1] = J[a][1] + dl[1][j] * a0[a];
+                    x[a] = fma(l[1][j], a0[a], x[a]);
+                    J[a][0] = fma(l[1][j], a1[a], J[a][0]);
+                    J[a][1] = fma(dl[1][j], a0[a], J[a][1]);
                 }
             }
         }
