@@ -12,7 +12,7 @@
 // Numerics: tensor-product Lagrange basis on the GLL nodes (order 1: -1,1; order 2: -1,0,1;
 // order 4: -1,-sqrt(3/7),0,sqrt(3/7),1), node index p = i + (n+1) j + (n+1)^2 k; Newton from
 // xi = 0 with the analytic Jacobian and a cofactor solve; converged when the largest update
-// component is < 1e-12, at most 25 updates; NaN when an iterate leaves [-10,10] or the iteration
+// component is < 1e-10, at most 25 updates; NaN when an iterate leaves [-10,10] or the iteration
 // does not converge.  Same operation order as the oracle, no fused multiply-add.
 //
 // One lane per target, control nodes streamed from L1/L2 each Newton step.  Targets are visited in
@@ -209,7 +209,7 @@ struct Gll {
                 if (!(fabs(xi[a]) <= 10.0)) bad = true;  // also catches NaN
             }
             if (bad) break;
-            if (step < 1e-12) return;
+            if (step < 1e-10) return;   // (the update just applied: what is left is its square)
         }
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xi[d] = NAN;

@@ -379,7 +379,7 @@ void mmo_knn_brute(const double *src, i64 nsrc, const double *pts, i64 npts,
 /*    fastest;                                                         */
 /*  - Newton from xi = 0 on x(xi) = sum_p L_p(xi) X_p, Jacobian by the */
 /*    analytic basis derivatives, cofactor solve; converged when the   */
-/*    largest component of the update is < 1e-12; at most 25 updates;  */
+/*    largest component of the update is < 1e-10; at most 25 updates;  */
 /*    NaN when the Jacobian is singular, an iterate leaves [-10,10]    */
 /*    or the iteration does not converge.                              */
 /* ================================================================== */
@@ -530,7 +530,7 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
             if (!(fabs(xi[a]) <= 10.0)) bad = 1; /* also catches NaN */
         }
         if (bad) break;
-        if (step < 1e-12) return;
+        if (step < 1e-10) return; /* (the update just applied: what is left is its square) */
     }
     for (int d = 0; d < dim; ++d) xi[d] = NAN;
 }
