@@ -1729,14 +1729,13 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         // ---- tile offsets: prefix sum over the cells in (layer, column) order ...
         int off[2], total;
         {
-            int incl0 = cnt[0], incl1 = cnt[1];
+            // (both prefix sums in one word -- a tile holds < 2^16 sources --: six dependent shuffles instead of twelve)
+            int packed = cnt[0] | (cnt[1] << 16);
             for (int d = 1; d < kWave; d <<= 1) {
-                const int a = __shfl_up(incl0, d), b = __shfl_up(incl1, d);
-                if (lane >= d) {
-                    incl0 += a;
-                    incl1 += b;
-                }
+                const int a = __shfl_up(packed, d);
+                if (lane >= d) packed += a;
             }
+            const int incl0 = packed & 0xffff, incl1 = packed >> 16;
             const int tot0 = __builtin_amdgcn_readlane(incl0, kWave - 1);
             const int nat_total = tot0 + __builtin_amdgcn_readlane(incl1, kWave - 1);
             const int nat0 = incl0 - cnt[0], nat1 = tot0 + incl1 - cnt[1];   // offsets without padding
@@ -1793,7 +1792,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         MM_STAMP(2);   // positions written
         // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, six records in flight per
         // lane (copying cell by cell was a chain of round trips)
-        constexpr int kTrips = 6;   // ~10 trips per tile: two groups, i.e. two global round trips (three with 4)
+        constexpr int kTrips = 11;  // ~10 trips per tile: all of them in flight at once, ONE global round trip
         for (int e0 = 0; e0 < total; e0 += kTrips * kWave) {
             int pos[kTrips];
             double2 xy[kTrips];
