@@ -2,7 +2,7 @@
 import json, sys
 for f in sys.argv[1:]:
     try:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
+        d = json.loads((sys.stdin if f == '-' else open(f)).read().strip().splitlines()[-1])
     except Exception as e:
         print("==", f, "unreadable:", e); continue
     print("==", f, "value %.4g" % d["value"], "ms/step %.3f" % d["ms_per_step"], "n_gpus", d["n_gpus"], "nfailed", d["nfailed"])
