@@ -583,6 +583,184 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- list mode, one WAVE per target ----------------------------------------------------------
+// The targets the fast kernels hand over are few (425 of 10M on the metric workload) and scattered; one lane
+// per target walking its rings record by record is a chain of ~250 dependent loads (0.19 ms for those 425
+// targets, a tail nothing overlaps).  Here the 64 lanes of a wave share one target: per ring
+//   runs   : lane j takes column j of the (2R+1)^2 block and looks up the extents of its one or two z-runs
+//            (the whole column outside the previous block, the two caps inside it), pruned like the scalar
+//            kernel by the k-th distance so far -- ONE round trip for the whole ring;
+//   scan   : the runs' records are numbered through by a prefix sum (offsets in LDS) and record t goes to
+//            lane t mod 64 (binary search over the <= 128 offsets); every lane keeps a private sorted list
+//            of the K best of ITS records, ordered by (d2, id) -- the union of the lists holds the K best;
+//   merge  : kout rounds of a wave-wide minimum over the lanes' list heads give the merged order (lane s
+//            keeps entry s) and the k-th distance for the stop test.
+// The set of records scanned is a superset of the scalar kernel's at every ring and the order (d2, id) is
+// total, so the result is the same list, bit for bit.
+constexpr int kWaveRuns = 2 * kWave;
+
+template <int K, typename IDX>
+__device__ __forceinline__ void knn_query_wave(const GridParams &g, i64 nsrc, const int *__restrict__ cell_start,
+                                               const double *__restrict__ sorted_xyz, double px, double py,
+                                               double pz, int ndim, int kout, IDX *__restrict__ idx_row,
+                                               double *__restrict__ dist_row, int *s_off, int *s_beg)
+{
+    const int lane = threadIdx.x;
+    const int cx = cell_coord(px, g.lox, g.ihx, g.nx);
+    const int cy = cell_coord(py, g.loy, g.ihy, g.ny);
+    const int cz = cell_coord(pz, g.loz, g.ihz, g.nz);
+    BestList<K> best;
+    best.init((int)nsrc);
+    double merged_d = INFINITY;   // lane s: entry s of the merged list
+    int merged_id = (int)nsrc;
+    double kth = INFINITY;        // its entry kout-1 (uniform)
+    int rprev = -1;
+    for (int R = 1;; ++R) {
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+        const int ncy = y1 - y0 + 1, ncols = (x1 - x0 + 1) * ncy;
+        for (int c0 = 0; c0 < ncols; c0 += kWave) {
+            // ---- runs of this chunk of columns
+            const int j = c0 + lane;
+            int beg[2] = {0, 0}, cnt[2] = {0, 0};
+            if (j < ncols) {
+                const int ix = x0 + j / ncy, iy = y0 + j % ncy;
+                const double cxl = g.lox + (double)ix * g.hx;
+                const double ddx = fmax(fmax(cxl - px, px - (cxl + g.hx)) - 1e-9 * g.hx, 0.0);
+                const double cyl = g.loy + (double)iy * g.hy;
+                const double ddy = fmax(fmax(cyl - py, py - (cyl + g.hy)) - 1e-9 * g.hy, 0.0);
+                const double lat2 = ddx * ddx + ddy * ddy;
+                const bool whole = max(abs(ix - cx), abs(iy - cy)) > rprev;
+                const int col = (ix * g.ny + iy) * g.nz;
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    int za, zb;
+                    if (whole) {
+                        za = z0;
+                        zb = part == 0 ? z1 : z0 - 1;
+                    } else if (part == 0) {
+                        za = z0;
+                        zb = min(cz - rprev - 1, g.nz - 1);
+                    } else {
+                        za = max(cz + rprev + 1, 0);
+                        zb = z1;
+                    }
+                    if (za > zb || lat2 > kth) continue;
+                    const double zl = g.loz + (double)za * g.hz, zh = g.loz + (double)(zb + 1) * g.hz;
+                    const double ddz = fmax(fmax(zl - pz, pz - zh) - 1e-9 * g.hz, 0.0);
+                    if (lat2 + ddz * ddz > kth) continue;
+                    beg[part] = cell_start[col + za];
+                    cnt[part] = cell_start[col + zb + 1] - beg[part];
+                }
+            }
+            const int incl = group_scan(cnt[0] + cnt[1], lane, kWave);
+            const int total = __shfl(incl, kWave - 1);
+            const int excl = incl - cnt[0] - cnt[1];
+            s_off[2 * lane] = excl;
+            s_off[2 * lane + 1] = excl + cnt[0];
+            s_beg[2 * lane] = beg[0];
+            s_beg[2 * lane + 1] = beg[1];
+            wave_sync();
+            // ---- the runs' records, one per lane and trip
+            for (int t0 = 0; t0 < total; t0 += kWave) {
+                const int t = t0 + lane;
+                int slot = 0;
+#pragma unroll
+                for (int step = kWaveRuns / 2; step >= 1; step >>= 1)
+                    if (s_off[slot + step] <= t) slot += step;   // last run starting at or before t (empty runs share offsets)
+                const bool active = t < total;
+                const i64 rec = active ? (i64)s_beg[slot] + (t - s_off[slot]) : 0;
+                const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + rec * kRec);
+                const double2 xy = r2[0], zw = r2[1];
+                const double dx = xy.x - px;
+                const double dy = xy.y - py;
+                const double dz = zw.x - pz;
+                double d2 = dx * dx;
+                d2 = d2 + dy * dy;
+                if (ndim > 2) d2 = d2 + dz * dz;
+                const int sid = record_id(zw.y);
+                if (active && before(d2, sid, best.d[K - 1], best.id[K - 1])) best.insert(d2, sid);
+            }
+            wave_sync();   // the offsets are rewritten by the next chunk
+        }
+        // ---- merged order of the lanes' lists
+        int head = 0;
+        for (int s = 0; s < kout; ++s) {
+            double hd = INFINITY;
+            int hi = (int)nsrc;
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+                if (u == head) {
+                    hd = best.d[u];
+                    hi = best.id[u];
+                }
+            double wd = hd;
+            int wi = hi;
+#pragma unroll
+            for (int off = kWave / 2; off >= 1; off >>= 1) {
+                const double od = __shfl_xor(wd, off);
+                const int oi = __shfl_xor(wi, off);
+                const bool lt = before(od, oi, wd, wi);
+                wd = lt ? od : wd;
+                wi = lt ? oi : wi;
+            }
+            if (hd == wd && hi == wi && head < K) ++head;   // ids are unique: one lane gives up its head (pads: any)
+            if (lane == s) {
+                merged_d = wd;
+                merged_id = wi;
+            }
+            kth = wd;
+        }
+        rprev = R;
+        const bool all_x = (cx - R <= 0) && (cx + R >= g.nx - 1);
+        const bool all_y = (cy - R <= 0) && (cy + R >= g.ny - 1);
+        const bool all_z = (cz - R <= 0) && (cz + R >= g.nz - 1);
+        if (all_x && all_y && all_z) break;
+        const double bound = block_bound(g, px, py, pz, cx, cy, cz, R);
+        if (bound > 0.0 && kth < bound * bound) break;
+    }
+    if (lane < kout) {
+        idx_row[lane] = (IDX)merged_id;
+        if (dist_row) dist_row[lane] = sqrt(merged_d);
+    }
+}
+
+template <int K, typename IDX>
+__global__ __launch_bounds__(kWave) void knn_list_wave_kernel(LevelTable lv, i64 nsrc,
+                                                              const double *__restrict__ pts, int ndim, int pstride,
+                                                              int kout, IDX *__restrict__ idx_out,
+                                                              double *__restrict__ dist_out,
+                                                              const int *__restrict__ list,
+                                                              const int *__restrict__ list_count, int keep_max)
+{
+    __shared__ int s_off[kWaveRuns];
+    __shared__ int s_beg[kWaveRuns];
+    const int total = *list_count;
+    for (int q = blockIdx.x; q < total; q += gridDim.x) {
+        const i64 i = list[q];
+        const double x = pts[i * pstride];
+        const double y = ndim > 1 ? pts[i * pstride + 1] : 0.0;
+        const double z = ndim > 2 ? pts[i * pstride + 2] : 0.0;
+        int l = 0;
+        for (; l < lv.n - 1; ++l) {   // (the level rule of knn_query_levels_kernel)
+            const GridParams &g = lv.g[l];
+            const int cx = cell_coord(x, g.lox, g.ihx, g.nx), cy = cell_coord(y, g.loy, g.ihy, g.ny);
+            const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
+            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+            int block = 0;
+            for (int ix = max(cx - 1, 0); ix <= min(cx + 1, g.nx - 1); ++ix)
+                for (int iy = max(cy - 1, 0); iy <= min(cy + 1, g.ny - 1); ++iy) {
+                    const int c = (ix * g.ny + iy) * g.nz;
+                    block += lv.cell_start[l][c + z1 + 1] - lv.cell_start[l][c + z0];
+                }
+            if (block <= 27 * keep_max) break;
+        }
+        knn_query_wave<K, IDX>(lv.g[l], nsrc, lv.cell_start[l], lv.sorted_xyz[l], x, y, z, ndim, kout,
+                               idx_out + i * kout, dist_out ? dist_out + i * kout : nullptr, s_off, s_beg);
+    }
+}
+
 template <int K, int CAP, typename IDX>
 __global__ __launch_bounds__(kWave, 4) void knn_cell_kernel(GridParams g, i64 nsrc,
                                                             const int *__restrict__ cell_start,
@@ -2083,6 +2261,29 @@ void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g
                        list_count, pstride);
 }
 
+__global__ __launch_bounds__(kBlock) void list_all_kernel(int *__restrict__ list, int *__restrict__ count, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) list[i] = (int)i;
+    if (i == 0) *count = (int)n;
+}
+
+// list mode, one wave per listed target (K <= 32: a lane's private list lives in registers)
+static bool list_kernel_is_scalar()
+{
+    static const bool scalar = getenv("MM_KNN_LIST_KERNEL") && !strcmp(getenv("MM_KNN_LIST_KERNEL"), "scalar");
+    return scalar;
+}
+
+template <int K, typename IDX>
+void launch_list_wave(mm_context *ctx, const LevelTable &lv, i64 nsrc, const double *pts, int ndim, int pstride,
+                      i64 npts, int kout, IDX *idx, double *dist, const int *list, const int *list_count, int keep_max)
+{
+    i64 grid = npts < 8192 ? npts : 8192;   // queue length is only known on the device: grid-stride
+    hipLaunchKernelGGL((knn_list_wave_kernel<K, IDX>), dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, lv, nsrc, pts,
+                       ndim, pstride, kout, idx, dist, list, list_count, keep_max);
+}
+
 // Strips of a level that hold targets, as workgroup ids of knn_strip_kernel (nsplit parts each).
 __global__ __launch_bounds__(kBlock) void strips_with_targets_kernel(GridParams g, const int *__restrict__ tstart,
                                                                      int nsplit, unsigned *__restrict__ list,
@@ -2507,6 +2708,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     LaneWork lane_work;
     bool use_lane = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK && npts >= 2 * ix->ncells;
     if (force_kernel) use_lane = strcmp(force_kernel, "lane") == 0 && !ix->fine && ix->dims[2] >= 2 && k <= kLaneMaxK;
+    // MM_KNN_FORCE_LIST: every target through the list-mode kernel (tests of that kernel only)
+    const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;   // (read per call: a test sets it)
+    if (force_list) use_lane = false;
     const bool sorted_rows = use_lane && tsorted_out != nullptr && !getenv("MM_KNN_UNSORTED_ROWS");
     lane_work.sorted_rows = sorted_rows ? 1 : 0;
     if (use_lane) {
@@ -2543,7 +2747,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
     const int *list = nullptr, *list_count = nullptr;   // level 0: every target
     int level = 0;
-    for (const mm_knn_index *l = ix; l; l = l->fine, ++level) {
+    if (force_list)
+        hipLaunchKernelGGL(list_all_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, fb_list, fb_count, npts);
+    for (const mm_knn_index *l = ix; l && !force_list; l = l->fine, ++level) {
         const GridParams gl = params_of(l);
         const i64 ncells = l->ncells;
         const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
@@ -2615,7 +2821,11 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     if (ggrid > 4096) ggrid = 4096;
 #define MM_GENERIC(KK)                                                                                               \
     do {                                                                                                             \
-        if (lv.n > 1)                                                                                                \
+        if (!list_kernel_is_scalar())                                                                                \
+            launch_list_wave<KK, IDX>(ctx, lv, ix->nsrc, sorted_rows ? *tsorted_out : pts_d, ix->ndim,                \
+                                      sorted_rows ? kRec : ix->ndim, npts, kout, idx_d, dist_d, fb_list, fb_count,   \
+                                      kListKeepMax);                                                                 \
+        else if (lv.n > 1)                                                                                                \
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, IDX>), dim3((unsigned)ggrid), dim3(kBlock), 0, ctx->stream, lv, \
                                ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax,     \
                                npts);                                                                       \
@@ -2654,7 +2864,10 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
     if (grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
 #define MM_LIST(KK)                                                                                                  \
     do {                                                                                                             \
-        if (lv.n > 1)                                                                                                \
+        if (KK <= 32 && !list_kernel_is_scalar())                                                                    \
+            launch_list_wave<(KK <= 32 ? KK : 32), int>(ctx, lv, ix->nsrc, pts_d, ix->ndim, ix->ndim, npts, kout,    \
+                                                        idx_d, (double *)nullptr, list, list_count, kListKeepMax);   \
+        else if (lv.n > 1)                                                                                                \
             hipLaunchKernelGGL((knn_query_levels_kernel<KK, int>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv, \
                                ix->nsrc, pts_d, ix->ndim, kout, idx_d, (double *)nullptr, list, list_count,   \
                                kListKeepMax, npts);                                                          \

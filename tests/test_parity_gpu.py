@@ -711,6 +711,34 @@ def test_knn_two_densities_like_a_locally_refined_mesh(ctx):
 
 
 @pytest.mark.gpu
+def test_knn_list_mode_one_wave_per_target(ctx, monkeypatch):
+    # the kernel that serves the targets the fast kernels hand over (and the locate stage's lazily fetched full
+    # lists), here given EVERY target: rings, pruning, the wave-wide merge, ties by index, pads, density levels
+    monkeypatch.setenv("MM_KNN_FORCE_LIST", "1")
+    rng = np.random.default_rng(21)
+    src = rng.uniform(size=(60_000, 3))
+    q = rng.uniform(-0.3, 1.3, size=(9_000, 3))
+    for k in (1, 8, 20, 32):
+        idx, dist = ctx.knn_build(src).query(q, k, want_dist=True)
+        ref, _ = O.knn_ckdtree(src, q, k, workers=-1)
+        diff = src[ref] - q[:, None, :]
+        refd = np.sqrt((diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2])
+        assert np.array_equal(idx.numpy(), ref) and np.array_equal(dist.numpy(), refd)
+    pa, ca = synth.hex_mesh(9, jitter=0.0)                       # exact ties
+    cen = O.centroid(ca, pa)
+    assert np.array_equal(ctx.knn_build(cen).query(pa, 20).numpy(), O.knn_brute(cen, pa, 20))
+    graded = rng.uniform(size=(80_000, 3)) ** 3.0                # several density levels
+    assert np.array_equal(ctx.knn_build(graded).query(q[:3000], 20).numpy(), O.knn_ckdtree(graded, q[:3000], 20)[0])
+    flat = rng.uniform(size=(5_000, 2))                          # 2-D
+    q2 = rng.uniform(-0.2, 1.2, size=(800, 2))
+    assert np.array_equal(ctx.knn_build(flat).query(q2, 16).numpy(), O.knn_ckdtree(flat, q2, 16)[0])
+    few = rng.uniform(size=(5, 3))                               # fewer sources than k: padded
+    idx, dist = ctx.knn_build(few).query(q[:50], 8, want_dist=True)
+    assert np.array_equal(idx.numpy()[:, :5], O.knn_brute(few, q[:50], 5)) and np.all(idx.numpy()[:, 5:] == 5)
+    assert np.all(np.isinf(dist.numpy()[:, 5:]))
+
+
+@pytest.mark.gpu
 def test_bad_arguments_are_refused_with_a_code_and_a_message(ctx):
     # the reference has no error channel at all; ours: negative MM_ERR_* and a
     # thread-local message, nothing launched, and the context stays usable
