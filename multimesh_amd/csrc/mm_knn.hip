@@ -467,10 +467,12 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
                                                            int kout, IDX *__restrict__ idx_out,
                                                            double *__restrict__ dist_out,
                                                            const int *__restrict__ list,
-                                                           const int *__restrict__ list_count, int pstride)
+                                                           const int *__restrict__ list_count, int pstride,
+                                                           int list_min)
 {
     // list != null: only the queued targets (stragglers of the fast kernel), grid-stride
     const i64 total = list ? (i64)*list_count : npts;
+    if (list && total <= list_min) return;   // short lists: knn_list_wave_kernel's
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride)
         knn_query_one<K, IDX>(g, nsrc, cell_start, sorted_xyz, pts, ndim, kout, idx_out, dist_out,
@@ -494,9 +496,10 @@ __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv,
                                                                   double *__restrict__ dist_out,
                                                                   const int *__restrict__ list,
                                                                   const int *__restrict__ list_count, int keep_max,
-                                                                  i64 npts)
+                                                                  i64 npts, int list_min)
 {
     const i64 total = list ? (i64)*list_count : npts;   // no list: every target (long lists, k > 32)
+    if (list && total <= list_min) return;   // short lists: knn_list_wave_kernel's
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
         const i64 i = list ? (i64)list[q] : q;
@@ -732,11 +735,13 @@ __global__ __launch_bounds__(kWave) void knn_list_wave_kernel(LevelTable lv, i64
                                                               int kout, IDX *__restrict__ idx_out,
                                                               double *__restrict__ dist_out,
                                                               const int *__restrict__ list,
-                                                              const int *__restrict__ list_count, int keep_max)
+                                                              const int *__restrict__ list_count, int keep_max,
+                                                              int list_max)
 {
     __shared__ int s_off[kWaveRuns];
     __shared__ int s_beg[kWaveRuns];
     const int total = *list_count;
+    if (total > list_max) return;   // long lists fill the chip one lane per target: the scalar kernels'
     for (int q = blockIdx.x; q < total; q += gridDim.x) {
         const i64 i = list[q];
         const double x = pts[i * pstride];
@@ -2251,14 +2256,15 @@ struct LaneWork {
 
 template <int K, typename IDX>
 void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, const double *pts, i64 npts,
-                    int kout, IDX *idx, double *dist, const int *list, const int *list_count, int pstride = 0)
+                    int kout, IDX *idx, double *dist, const int *list, const int *list_count, int pstride = 0,
+                    int list_min = -1)
 {
     if (pstride == 0) pstride = ix->ndim;
     i64 grid = (npts + kBlock - 1) / kBlock;
     if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
     hipLaunchKernelGGL((knn_query_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
                        ix->cell_start, ix->sorted_xyz, pts, npts, ix->ndim, kout, idx, dist, list,
-                       list_count, pstride);
+                       list_count, pstride, list_min);
 }
 
 __global__ __launch_bounds__(kBlock) void list_all_kernel(int *__restrict__ list, int *__restrict__ count, i64 n)
@@ -2268,20 +2274,39 @@ __global__ __launch_bounds__(kBlock) void list_all_kernel(int *__restrict__ list
     if (i == 0) *count = (int)n;
 }
 
-// list mode, one wave per listed target (K <= 32: a lane's private list lives in registers)
-static bool list_kernel_is_scalar()
+// List mode.  The length of the list is only known on the device, and the two kernels suit opposite ends: a
+// handful of stragglers is a latency problem (one WAVE per target: 0.02 ms instead of 0.19 ms for the metric
+// workload's 425), hundreds of thousands fill the chip one LANE per target (cfg5's shape hands over every
+// target whose 20th neighbour lies outside the 27-cell window, 120 k of 7.2 M: 1.9 ms by waves -- 16 ns per
+// target -- against 0.35 ms by lanes; the curves cross near 12 k targets).
+// Both kernels are launched; each returns at once when the length is on the other's side of the threshold.
+// K > 32: the scalar kernel only (a lane's private list must stay in registers).
+static int list_wave_max()
 {
-    static const bool scalar = getenv("MM_KNN_LIST_KERNEL") && !strcmp(getenv("MM_KNN_LIST_KERNEL"), "scalar");
-    return scalar;
+    static const int v = getenv("MM_KNN_LIST_WAVE_MAX") ? atoi(getenv("MM_KNN_LIST_WAVE_MAX")) : 8192;
+    return v;
 }
 
 template <int K, typename IDX>
-void launch_list_wave(mm_context *ctx, const LevelTable &lv, i64 nsrc, const double *pts, int ndim, int pstride,
-                      i64 npts, int kout, IDX *idx, double *dist, const int *list, const int *list_count, int keep_max)
+void launch_list(mm_context *ctx, const mm_knn_index *ix, const LevelTable &lv, const double *pts, int pstride, i64 npts,
+                 int kout, IDX *idx, double *dist, const int *list, const int *list_count, int keep_max)
 {
-    i64 grid = npts < 8192 ? npts : 8192;   // queue length is only known on the device: grid-stride
-    hipLaunchKernelGGL((knn_list_wave_kernel<K, IDX>), dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, lv, nsrc, pts,
-                       ndim, pstride, kout, idx, dist, list, list_count, keep_max);
+    const int wave_max = K <= 32 ? list_wave_max() : -1;
+    if (K <= 32 && wave_max >= 0) {
+        const i64 cap = npts < wave_max ? npts : wave_max;
+        const i64 grid = cap < 8192 ? (cap > 0 ? cap : 1) : 8192;
+        hipLaunchKernelGGL((knn_list_wave_kernel<(K <= 32 ? K : 32), IDX>), dim3((unsigned)grid), dim3(kWave), 0,
+                           ctx->stream, lv, ix->nsrc, pts, ix->ndim, pstride, kout, idx, dist, list, list_count,
+                           keep_max, wave_max);
+    }
+    if (npts <= wave_max) return;   // the list cannot be longer than the query
+    i64 grid = (npts + kBlock - 1) / kBlock;
+    if (grid > 4096) grid = 4096;
+    if (lv.n > 1)
+        hipLaunchKernelGGL((knn_query_levels_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv,
+                           ix->nsrc, pts, ix->ndim, kout, idx, dist, list, list_count, keep_max, npts, wave_max);
+    else
+        launch_generic<K, IDX>(ctx, ix, lv.g[0], pts, npts, kout, idx, dist, list, list_count, pstride, wave_max);
 }
 
 // Strips of a level that hold targets, as workgroup ids of knn_strip_kernel (nsplit parts each).
@@ -2671,11 +2696,11 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             if (k <= 40)
                 hipLaunchKernelGGL((knn_query_levels_kernel<40, IDX>), grid, block, 0, ctx->stream, lv, ix->nsrc, pts_d,
                                    ix->ndim, kout, idx_d, dist_d, (const int *)nullptr, (const int *)nullptr,
-                                   kListKeepMax, npts);
+                                   kListKeepMax, npts, -1);
             else
                 hipLaunchKernelGGL((knn_query_levels_kernel<MM_KNN_MAX_K, IDX>), grid, block, 0, ctx->stream, lv, ix->nsrc,
                                    pts_d, ix->ndim, kout, idx_d, dist_d, (const int *)nullptr, (const int *)nullptr,
-                                   kListKeepMax, npts);
+                                   kListKeepMax, npts, -1);
         } else if (k <= 40) {
             launch_generic<40, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, nullptr, nullptr);
         } else {
@@ -2817,23 +2842,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         lv.sorted_xyz[lv.n] = l->sorted_xyz;
         ++lv.n;
     }
-    i64 ggrid = (npts + kBlock - 1) / kBlock;
-    if (ggrid > 4096) ggrid = 4096;
 #define MM_GENERIC(KK)                                                                                               \
-    do {                                                                                                             \
-        if (!list_kernel_is_scalar())                                                                                \
-            launch_list_wave<KK, IDX>(ctx, lv, ix->nsrc, sorted_rows ? *tsorted_out : pts_d, ix->ndim,                \
-                                      sorted_rows ? kRec : ix->ndim, npts, kout, idx_d, dist_d, fb_list, fb_count,   \
-                                      kListKeepMax);                                                                 \
-        else if (lv.n > 1)                                                                                                \
-            hipLaunchKernelGGL((knn_query_levels_kernel<KK, IDX>), dim3((unsigned)ggrid), dim3(kBlock), 0, ctx->stream, lv, \
-                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, dist_d, fb_list, fb_count, kListKeepMax,     \
-                               npts);                                                                       \
-        else if (sorted_rows)                                                                                        \
-            launch_generic<KK, IDX>(ctx, ix, g, *tsorted_out, npts, kout, idx_d, dist_d, fb_list, fb_count, kRec);    \
-        else                                                                                                         \
-            launch_generic<KK, IDX>(ctx, ix, g, pts_d, npts, kout, idx_d, dist_d, fb_list, fb_count);                \
-    } while (0)
+    launch_list<KK, IDX>(ctx, ix, lv, sorted_rows ? *tsorted_out : pts_d, sorted_rows ? kRec : ix->ndim, npts, kout,  \
+                         idx_d, dist_d, fb_list, fb_count, kListKeepMax)
     if (k <= 1) MM_GENERIC(1);
     else if (k <= 2) MM_GENERIC(2);
     else if (k <= 4) MM_GENERIC(4);
@@ -2860,20 +2871,9 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
         lv.sorted_xyz[lv.n] = l->sorted_xyz;
         ++lv.n;
     }
-    i64 grid = (npts + kBlock - 1) / kBlock;
-    if (grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
 #define MM_LIST(KK)                                                                                                  \
-    do {                                                                                                             \
-        if (KK <= 32 && !list_kernel_is_scalar())                                                                    \
-            launch_list_wave<(KK <= 32 ? KK : 32), int>(ctx, lv, ix->nsrc, pts_d, ix->ndim, ix->ndim, npts, kout,    \
-                                                        idx_d, (double *)nullptr, list, list_count, kListKeepMax);   \
-        else if (lv.n > 1)                                                                                                \
-            hipLaunchKernelGGL((knn_query_levels_kernel<KK, int>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv, \
-                               ix->nsrc, pts_d, ix->ndim, kout, idx_d, (double *)nullptr, list, list_count,   \
-                               kListKeepMax, npts);                                                          \
-        else                                                                                                         \
-            launch_generic<KK, int>(ctx, ix, lv.g[0], pts_d, npts, kout, idx_d, nullptr, list, list_count);          \
-    } while (0)
+    launch_list<KK, int>(ctx, ix, lv, pts_d, ix->ndim, npts, kout, idx_d, (double *)nullptr, list, list_count,       \
+                         kListKeepMax)
     if (k <= 8) MM_LIST(8);
     else if (k <= 16) MM_LIST(16);
     else if (k <= 20) MM_LIST(20);
