@@ -103,19 +103,25 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const double *__re
 __global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
                                                          double *__restrict__ out)
 {
-    // one wave: lanes stride over the per-block partials, then a butterfly reduction
-    for (int a = 0; a < 6; ++a) {
-        double v = a < 3 ? INFINITY : -INFINITY;
-        for (int b = threadIdx.x; b < nblocks; b += 64) {
-            const double p = partial[b * 6 + a];
-            v = a < 3 ? fmin(v, p) : fmax(v, p);
+    // one wave per component (grid 6): lanes stride over the per-block partials, four independent loads in
+    // flight each, then a butterfly reduction
+    const int a = blockIdx.x;
+    const double init = a < 3 ? INFINITY : -INFINITY;
+    double v[4] = {init, init, init, init};
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + 64 * u;
+            const double p = bb < nblocks ? partial[bb * 6 + a] : init;
+            v[u] = a < 3 ? fmin(v[u], p) : fmax(v[u], p);
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(v, off);
-            v = a < 3 ? fmin(v, o) : fmax(v, o);
-        }
-        if (threadIdx.x == 0) out[a] = v;
     }
+    double r = a < 3 ? fmin(fmin(v[0], v[1]), fmin(v[2], v[3])) : fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(r, off);
+        r = a < 3 ? fmin(r, o) : fmax(r, o);
+    }
+    if (threadIdx.x == 0) out[a] = r;
 }
 
 // ---- cell assignment ----------------------------------------------------------------
@@ -2623,11 +2629,11 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
         if (box_partial_d) {
             // the producer of the sources (the fused pipeline's centroid kernel) already left partials
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
         } else {
             hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
                                (int)ndim, partial);
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
         }
         hipError_t e = hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

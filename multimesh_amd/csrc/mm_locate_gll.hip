@@ -321,6 +321,7 @@ __device__ __forceinline__ void gll_emit(const GllEmit &em, i64 i, i64 e, const 
 // arrays.  Re-queue entries are batched per wave in LDS (one global atomic per ~200 entries).
 constexpr int kGllWaveQueue = 256;
 constexpr int kGllLazyK = 8;   // candidates asked of the kNN stage up front by mm_interpolate_gll
+constexpr int kGllWalkFrom = 3; // passes that advance one candidate before the lanes walk their lists
 
 template <int ORDER, int DIM, typename IDX>
 __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavai
                                                              const int *__restrict__ q_in_count,
                                                              int2 *__restrict__ q_out, int *__restrict__ q_out_count,
                                                              double *__restrict__ best_state,   // [N][DIM+1]
-                                                             i64 *__restrict__ best_elem_state)  // [N]
+                                                             i64 *__restrict__ best_elem_state,  // [N]
+                                                             int walk)
 {
     using G = Gll<ORDER, DIM>;
     constexpr int P = G::P;
@@ -376,14 +378,15 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavai
                 for (int d = 0; d < DIM; ++d) best_xi[d] = best_state[i * (DIM + 1) + 1 + d];
                 best_elem = best_elem_state[i];
             }
-            // next valid candidate; this array holds the first kavail <= k of the target's list
-            while (j < kavail) {
-                const i64 e = (i64)nn[i * kavail + j];
-                if (e >= 0 && e < nelem) break;
-                ++j;
-            }
             bool found = false;
-            if (j < kavail) {
+            do {   // one candidate, or (walk) one after the other until the point is found or the list ends
+                // next valid candidate; this array holds the first kavail <= k of the target's list
+                while (j < kavail) {
+                    const i64 e = (i64)nn[i * kavail + j];
+                    if (e >= 0 && e < nelem) break;
+                    ++j;
+                }
+                if (j >= kavail) break;
                 const i64 e = (i64)nn[i * kavail + j];
                 double xi[DIM];
                 G::inverse_transform(pnt, gll_points + e * (i64)(P * DIM), xi);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavai
                     }
                 }
                 ++j;
-            }
+            } while (walk && !found);
             if (!found) {
                 if (j < k) {
                     requeue = true;   // also: the short list is used up and the full one is needed
@@ -669,35 +672,47 @@ int launch_locate(mm_context *ctx, i64 k, int kavail, i64 npoints, const IDX *nn
                   const GllLazy *lazy, int *id_list)
 {
     const i64 full_grid = (npoints + 63) / 64;
-    const i64 npasses = k > 0 ? k : 1;
-    for (i64 p = 0; p < npasses; ++p) {
-        const int2 *q_in = p == 0 ? nullptr : ((p & 1) ? qa : qb);
-        int2 *q_out = (p & 1) ? qb : qa;
+    // Pass c reads queue c (pass 0: every target) and advances each open target by ONE candidate -- so that a
+    // wave never waits for its unluckiest lane while most lanes still have work -- until pass kGllWalkFrom: by
+    // then the queue is a sliver of the targets (mostly points that lie outside every candidate and will use
+    // up their list) and each further launch would cost a full Newton solve of latency over a nearly empty
+    // chip (17 such passes: 2.9 of cfg5's 8.6 ms), so from there a lane walks its list to the end.  With lazy
+    // lists the walk ends at the short list's end, the open targets' full lists are fetched once, and one
+    // more walking pass finishes them.
+    static const int walk_from = getenv("MM_GLL_WALK_FROM") ? atoi(getenv("MM_GLL_WALK_FROM")) : kGllWalkFrom;
+    i64 jdone = 0;        // candidates every open target is past
+    bool full = false;    // the passes read the full lists (lazy only)
+    for (int c = 0; c == 0 || jdone < k; ++c) {
+        const int2 *q_in = c == 0 ? nullptr : ((c & 1) ? qa : qb);
+        int2 *q_out = (c & 1) ? qb : qa;
         // persistent waves; later passes only know their size on the device
-        i64 grid = full_grid >> (p < 6 ? p : 6);
+        i64 grid = full_grid >> (c < 6 ? c : 6);
         if (grid > 16384) grid = 16384;
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
-        const bool full_lists = lazy && p >= kavail;
-        if (lazy && p == kavail) {
-            hipLaunchKernelGGL(gll_queue_ids_kernel, dim3(64), dim3(256), 0, ctx->stream, q_in, counters + p, id_list);
-            int rc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, k, lazy->nn_full, id_list, counters + p);
+        if (lazy && !full && jdone >= kavail) {
+            hipLaunchKernelGGL(gll_queue_ids_kernel, dim3(64), dim3(256), 0, ctx->stream, q_in, counters + c, id_list);
+            int rc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, k, lazy->nn_full, id_list, counters + c);
             if (rc != MM_OK) return rc;
+            full = true;
         }
-        if (p == 0 && k > 0 && nelem > 0) {
+        const i64 avail = full ? k : (i64)kavail;
+        const int walk = c >= walk_from ? 1 : 0;
+        if (c == 0 && k > 0 && nelem > 0) {
             hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0,
                                ctx->stream, k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, order, q_out,
-                               counters + p + 1, best_state, best_elem_state);
-        } else if (full_lists) {
+                               counters + c + 1, best_state, best_elem_state);
+        } else if (full) {
             hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, int>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
                                k, (int)k, npoints, (const int *)lazy->nn_full, gll, nelem, pts, tol, snap, em, nmiss,
-                               (const int *)nullptr, q_in, counters + p, q_out, counters + p + 1, best_state,
-                               best_elem_state);
+                               (const int *)nullptr, q_in, counters + c, q_out, counters + c + 1, best_state,
+                               best_elem_state, walk);
         } else {
             hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
-                               k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, p == 0 ? order : nullptr,
-                               q_in, p == 0 ? nullptr : counters + p, q_out, counters + p + 1, best_state,
-                               best_elem_state);
+                               k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, c == 0 ? order : nullptr,
+                               q_in, c == 0 ? nullptr : counters + c, q_out, counters + c + 1, best_state,
+                               best_elem_state, walk);
         }
+        jdone = (walk && c > 0) || (walk && !(k > 0 && nelem > 0)) ? avail : jdone + 1;
     }
     return MM_OK;
 }
