@@ -10,8 +10,12 @@ Covered (hex8, the path the reference implements in its own C):
   * :func:`interpolate_mesh_a_to_b`  -- reference scripts/cli.py:35-104
   * :func:`interpolate_to_points`    -- reference api.py:320-350 / interpolator.py:931-977
   * :func:`interpolate_to_mesh`      -- reference api.py:353-393
-The GLL (salvus.fem backed) entry points keep their names and raise NotImplementedError naming the
-SURVEY.md §8 row they wait for.
+GLL paths (the reference's salvus.fem numerics restated): the array cores
+:func:`interpolate_gll_to_points`, :func:`interpolate_gll_to_gll`, :func:`interpolate_gll_to_gll_layered`,
+:func:`interpolate_hex8_to_gll`, :func:`interpolate_gll_to_nodes`, :func:`query_gll_model`, and over them the
+file-level drivers under the reference's names -- :func:`query_model`, :func:`exodus_2_gll`,
+:func:`gll_2_exodus`, :func:`gll_2_gll`, :func:`gll_2_gll_layered_multi_two` -- reading and writing meshes
+through :mod:`multimesh_amd.io`.
 """
 from __future__ import annotations
 
@@ -241,7 +245,8 @@ def interpolate_gll_to_gll(mesh_a: GllMesh, target_gll_points, params_to_interp,
     return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(params_to_interp), tgt.shape[0], tgt.shape[1])
 
 
-def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to_search=20, context=None):
+def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to_search=20, context=None,
+                            return_nfailed=False):
     """The array core of ``exodus_2_gll`` (reference cli.py:128-257, interpolator.py:60-150): the
     reference runs its hex8 path once per GLL slot (125 times at order 4) over points that repeat on
     shared faces, edges and corners; here the target mesh's element-nodal points are reduced to
@@ -257,7 +262,8 @@ def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to
         print(nfailed, "points could not find an enclosing element. These points will be set to zero. "
                        "Please check your domain or the interpolation tuning parameters")
     vals = vals.numpy()                                              # [U, C]
-    return np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(list(params)), tgt.shape[0], tgt.shape[1])
+    out = np.ascontiguousarray(vals[inv.numpy()].T).reshape(len(list(params)), tgt.shape[0], tgt.shape[1])
+    return (out, nfailed) if return_nfailed else out
 
 
 def assess_layers(layer_ids, layers):
@@ -402,12 +408,27 @@ def interpolate_gll_to_nodes(gll_points, gll_data, points, shape_order=4, nelem_
     return ctx.gather_elem(fields, elem, coeffs).numpy()
 
 
+def _gll_operator_over_all_points(ctx, gll_points, points, nelem_to_search, ignore_hard_elements):
+    """``find_gll_coeffs`` as ``query_model`` and ``gll_2_gll`` drive it (reference interpolator.py:91-126,
+    :742-786): a tree over ALL GLL points (not the centroids), the ``nelem_to_search`` nearest points per
+    coordinate mapped to their elements by ``floor(index / P)`` (an element can appear several times in a
+    list), then the bounding-box acceptance loop (:1409-1473).  Returns device arrays ``(element, coeffs)``."""
+    nelem, P, dim = gll_points.shape
+    gll_order = int(round(P ** (1.0 / dim))) - 1
+    tree = ctx.knn_build(gll_points.reshape(nelem * P, dim))
+    pts = ctx.asdevice(points if hasattr(points, "numpy") else np.ascontiguousarray(points, dtype=np.float64),
+                       np.float64)
+    nearest = np.floor(tree.query(pts, nelem_to_search).numpy() / P).astype(np.int64)
+    elem, coeffs, hard = ctx.locate_gll_bbox(gll_order, nearest, gll_points, pts)
+    if hard and not ignore_hard_elements:
+        raise ValueError("Can't find an appropriate element.")
+    return elem, coeffs
+
+
 def query_gll_model(gll_points, gll_data, coordinates, nelem_to_search=20, ignore_hard_elements=False, context=None):
     """The array core of ``query_model`` (reference interpolator.py:60-139) after its file read and
-    ``latlondepth_to_xyz``: a tree over ALL GLL points (not the centroids), the ``nelem_to_search``
-    nearest points per coordinate mapped to their elements by ``floor(index / P)`` (an element can
-    appear several times in a list), ``find_gll_coeffs`` = the bounding-box acceptance loop
-    (:1409-1473), then ``np.sum(original_data[elements] * coeffs, axis=2)``.
+    ``latlondepth_to_xyz``: :func:`_gll_operator_over_all_points`, then
+    ``np.sum(original_data[elements] * coeffs, axis=2)``.
     ``gll_points`` f64[E, P, dim], ``gll_data`` f64[E, C, P], ``coordinates`` f64[N, dim] (Cartesian)
     -> values f64[N, C].  Like the reference it raises ``ValueError`` when no candidate element
     admits an inverse transform, unless ``ignore_hard_elements``.  Equidistant points (the copies of
@@ -415,30 +436,164 @@ def query_gll_model(gll_points, gll_data, coordinates, nelem_to_search=20, ignor
     unspecified."""
     ctx = context or default_context()
     gll_points = np.ascontiguousarray(gll_points, dtype=np.float64)
-    nelem, P, dim = gll_points.shape
-    gll_order = int(round(P ** (1.0 / dim))) - 1
-    tree = ctx.knn_build(gll_points.reshape(nelem * P, dim))
-    pts = ctx.asdevice(np.ascontiguousarray(coordinates, dtype=np.float64), np.float64)
-    nearest = np.floor(tree.query(pts, nelem_to_search).numpy() / P).astype(np.int64)
-    elem, coeffs, hard = ctx.locate_gll_bbox(gll_order, nearest, gll_points, pts)
-    if hard and not ignore_hard_elements:
-        raise ValueError("Can't find an appropriate element.")
+    elem, coeffs = _gll_operator_over_all_points(ctx, gll_points, coordinates, nelem_to_search, ignore_hard_elements)
     fields = np.ascontiguousarray(np.asarray(gll_data, dtype=np.float64).transpose(1, 0, 2))   # [C, E, P]
     return ctx.gather_elem(fields, elem, coeffs).numpy()
 
 
+# ---------------------------------------------------------------------------------------------------
+# File-level drivers: the reference's names and arguments; files through multimesh_amd.io (h5py for HDF5
+# paths, scipy's netCDF reader for classic Exodus files), or already open h5py-like / mesh objects in
+# place of the paths.  The work itself is the array cores above.
+def query_model(coordinates, model, nelem_to_search=20, parameters="TTI", model_path="MODEL/data",
+                coordinates_path="MODEL/coordinates", context=None):
+    """Model parameters at ``coordinates`` f64[N, 3] = (latitude, longitude, depth in m) from a Salvus GLL
+    model file (reference api.py:13-58, interpolator.py:60-139) -> f64[N, nparam] in the file's parameter
+    order.  ``parameters`` is accepted and ignored, as in the reference."""
+    from . import io as mio
+
+    start = time.time()
+    points, data, _ = mio.load_hdf5_params_to_memory(model, model_path, coordinates_path)
+    coordinates = np.asarray(coordinates, dtype=np.float64)
+    assert coordinates.ndim == 2 and coordinates.shape[1] == 3, "Make sure coordinates array has shape N,3"
+    values = query_gll_model(points, data, latlondepth_to_xyz(coordinates), nelem_to_search, context=context)
+    _report(start)
+    return values
+
+
+def exodus_2_gll(mesh, gll_model, gll_order=4, dimensions=3, nelem_to_search=20, parameters="TTI",
+                 model_path="MODEL/data", coordinates_path="MODEL/coordinates", context=None):
+    """Nodal parameters of an exodus hex8 mesh onto the GLL points of an HDF5 model, written to
+    ``gll_model[model_path]`` as f64[nelem, nparam, P] with fresh dimension labels (reference api.py:61-103,
+    interpolator.py:142-224; ``gll_order`` / ``dimensions`` are read off the coordinates).  ``mesh``: an
+    Exodus file or a mesh object with ``points``, ``connectivity``, ``get_nodal_field``; ``gll_model``: an HDF5
+    file or an open writable h5py-like object."""
+    from . import io as mio
+
+    start = time.time()
+    exodus = mio.Exodus(mesh) if isinstance(mesh, (str, os.PathLike)) else mesh
+    parameters = mio.pick_parameters(parameters)
+    mesh_a = HexMesh(exodus.points, exodus.connectivity, {p: exodus.get_nodal_field(p) for p in parameters})
+    with mio.open_h5(gll_model, "r+") as gll:
+        gll_coords = np.array(gll[coordinates_path][:], dtype=np.float64)
+        values, nfailed = interpolate_hex8_to_gll(mesh_a, gll_coords, parameters, nelem_to_search, context=context,
+                                                  return_nfailed=True)
+        assert nfailed == 0, f"{nfailed} points could not be interpolated."
+        mio.remove_and_create_empty_dataset(gll, parameters, model_path, coordinates_path)
+        gll[model_path][:, :, :] = values.transpose(1, 0, 2)
+    _report(start)
+
+
+def gll_2_exodus(gll_model, exodus_model, gll_order=4, dimensions=3, nelem_to_search=20, parameters="TTI",
+                 model_path="MODEL/data", coordinates_path="MODEL/coordinates", gradient=False, context=None):
+    """Every parameter of a GLL model onto the nodes of an exodus mesh, attached as its nodal fields
+    (reference api.py:277-317, interpolator.py:227-285; like the reference, ``parameters`` is replaced by
+    the model's own list and the exodus variables must exist).  ``exodus_model``: an Exodus file (opened
+    in mode "a") or a mesh object with ``points`` and ``attach_field``."""
+    from . import io as mio
+
+    start = time.time()
+    with mio.open_h5(gll_model, "r") as gll:
+        gll_points = np.array(gll[coordinates_path][:], dtype=np.float64)
+        gll_data = np.array(gll[model_path][:])
+        parameters = mio.dimension_labels(gll[model_path], 1)
+    exodus = mio.Exodus(exodus_model, mode="a") if isinstance(exodus_model, (str, os.PathLike)) else exodus_model
+    shape_order = int(round(gll_points.shape[1] ** (1.0 / gll_points.shape[2]))) - 1
+    values = interpolate_gll_to_nodes(gll_points, gll_data, exodus.points, shape_order, nelem_to_search, context)
+    for i, param in enumerate(parameters):
+        exodus.attach_field(param, values[:, i])
+    _report(start)
+
+
+def gll_2_gll(from_gll, to_gll, nelem_to_search=20, parameters="ISO", from_model_path="MODEL/data",
+              to_model_path="MODEL/data", from_coordinates_path="MODEL/coordinates",
+              to_coordinates_path="MODEL/coordinates", gradient=False, stored_array=None, context=None):
+    """All parameters of one GLL model onto the GLL points of another, written to ``to_gll[to_model_path]``
+    (reference api.py:106-155, interpolator.py:621-852): unique target points (device ``np.unique``),
+    :func:`_gll_operator_over_all_points` with hard elements ignored, ``values[recon]`` scattered back, fluid
+    elements and solid elements that caught a zero VS keep their previous values unless ``gradient``.  Like
+    the reference, ``parameters`` is replaced by the source model's own list.  ``stored_array``: directory of
+    ``elements.npy`` + ``coeffs.npy``; ``coeffs.npy`` is written as f64[1, P, U] -- the reference writes
+    ``nparam`` identical copies [nparam, P, U] and broadcasts either on load -- and both are read."""
+    from . import io as mio
+
+    start = time.time()
+    ctx = context or default_context()
+    print("Initialization stage")
+    print(f"Stored array: {stored_array}")
+    original_points, original_data, parameters = mio.load_hdf5_params_to_memory(from_gll, from_model_path,
+                                                                                from_coordinates_path)
+    with mio.open_h5(to_gll, "r+") as new:
+        new_points = np.array(new[to_coordinates_path][:], dtype=np.float64)
+        elem_params = mio.dimension_labels(new["MODEL/element_data"], 1)
+        fluid_elements = np.array(new["MODEL/element_data"][:, elem_params.index("fluid")]).astype(bool)
+        solid_elements = np.invert(fluid_elements)
+        new_values = np.array(new[to_model_path][:], dtype=np.float64)
+        unique_new_points, recon = ctx.unique_points(new_points.reshape(-1, new_points.shape[2]))
+        stored = load_stored_operator(stored_array)
+        if stored is not None:
+            print("Matrix was already stored. Will use that one")
+            element, coeffs = stored
+            element = np.asarray(element).astype(np.int64)
+            if coeffs.ndim == 3:                       # [nparam or 1, P, U] as the reference stores it
+                coeffs = np.ascontiguousarray(coeffs[0].T)
+        else:
+            print("Now we start interpolating")
+            element, coeffs = _gll_operator_over_all_points(ctx, np.ascontiguousarray(original_points),
+                                                            unique_new_points, nelem_to_search, True)
+            if stored_array:
+                save_stored_operator(stored_array, element.numpy(), coeffs.numpy().T[None, :, :])
+        fields = np.ascontiguousarray(np.asarray(original_data, dtype=np.float64).transpose(1, 0, 2))   # [C, E, P]
+        unique_values = ctx.gather_elem(fields, element, coeffs).numpy()                                # [U, C]
+        values = np.ascontiguousarray(unique_values[recon.numpy()].reshape(new_points.shape[0], new_points.shape[1],
+                                                                          len(parameters)).swapaxes(1, 2))
+        if not gradient:
+            if new_values.shape != values.shape:
+                raise ValueError("the receiving model must already hold the source model's parameters "
+                                 f"({values.shape[1]}), it has {new_values.shape[1]}")
+            values = fix_fluid_solid(values, new_values, solid_elements, parameters, context=ctx)
+        mio.remove_and_create_empty_dataset(new, parameters, to_model_path, to_coordinates_path)
+        new[to_model_path][:, :, :] = values
+    _report(start)
+
+
+def gll_2_gll_layered_multi_two(from_gll, to_gll, layers, nelem_to_search=30, parameters="all", stored_array=None,
+                                make_spherical=False, tolerance=1.05, context=None):
+    """Layer by layer, GLL model to GLL model, through the fast Salvus-mesh reader (reference api.py:645-699,
+    interpolator.py:980-1082): the ``layer`` elemental field of both meshes, :func:`interpolate_gll_to_gll_layered`,
+    every parameter attached to ``to_gll``.  ``layers``: "all" or a list of layer numbers (the Earth presets
+    need mesh metadata); ``make_spherical`` is Earth-specific and refused."""
+    from . import io as mio
+
+    if make_spherical:
+        raise NotImplementedError("map_to_sphere (reference interpolator.py:1085-1144) is Earth-specific "
+                                  "(out of scope, SURVEY.md §8)")
+    start = time.time()
+    original_mesh = mio.SalvusMesh(from_gll, fast_mode=False)
+    new_mesh = mio.SalvusMesh(to_gll, fast_mode=False)
+    if isinstance(parameters, str) and parameters == "all":
+        parameters = list(original_mesh.element_nodal_fields.keys())
+    parameters = mio.pick_parameters(parameters)
+    mesh_a = GllMesh(original_mesh.points, original_mesh.shape_order,
+                     {p: original_mesh.element_nodal_fields[p] for p in parameters})
+    existing = np.stack([new_mesh.element_nodal_fields[p] for p in parameters])
+    values = interpolate_gll_to_gll_layered(mesh_a, original_mesh.elemental_fields["layer"], new_mesh.points,
+                                            new_mesh.elemental_fields["layer"], parameters, layers=layers,
+                                            nelem_to_search=nelem_to_search, tolerance=tolerance,
+                                            stored_array=stored_array, existing=existing, context=context)
+    for i, param in enumerate(parameters):
+        new_mesh.attach_field(name=param, data=values[i])
+    _report(start)
+
+
 def _gll(name, row):
     def f(*args, **kwargs):
-        raise NotImplementedError(f"{name}: file-level driver (HDF5 / exodus I/O through h5py, pyexodus and salvus, "
-                                  f"none of which is available here) -- SURVEY.md §8 row {row}")
+        raise NotImplementedError(f"{name}: {row}")
     f.__name__ = name
     return f
 
 
-exodus_2_gll = _gll("exodus_2_gll", "§8f-2 (file I/O) -- array core: interpolate_hex8_to_gll")
-gll_2_gll = _gll("gll_2_gll", "A10 -- array core: interpolate_gll_to_gll; file I/O is §8f-2")
-gll_2_gll_layered = _gll("gll_2_gll_layered", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
-gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
-gll_2_gll_layered_multi_two = _gll("gll_2_gll_layered_multi_two", "§8f-2 (file I/O) -- array core: interpolate_gll_to_gll_layered")
-gll_2_exodus = _gll("gll_2_exodus", "§8f-2 (file I/O) -- array core: interpolate_gll_to_nodes")
-query_model = _gll("query_model", "§8f-2 (file I/O) -- array core: query_gll_model")
+gll_2_gll_layered = _gll("gll_2_gll_layered", "superseded in the reference by gll_2_gll_layered_multi_two, which is "
+                         "implemented here (same arguments); array core: interpolate_gll_to_gll_layered")
+gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "superseded in the reference by gll_2_gll_layered_multi_two, "
+                               "which is implemented here (same arguments); array core: interpolate_gll_to_gll_layered")
