@@ -455,11 +455,11 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavai
 }
 
 // First pass with the control nodes in LDS.  Targets arrive sorted by their first candidate element
-// (~90 per element at cfg5's shape), so the 64 lanes of a wave need one or two elements: those are
-// copied into LDS once per solve (coalesced) and every Newton step reads them from there -- all lanes
-// of an element the same address (broadcast) -- instead of going back to L1/L2 for 3 KB per step.  A
-// wave with more than two distinct elements (thinly populated elements) takes further turns of the
-// stage/solve loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
+// (~90 per element at cfg5's shape), so the 64 lanes of a wave need one to three elements: up to kStaged
+// of them are copied into LDS once per solve (coalesced) and every Newton step reads them from there -- all
+// lanes of an element the same address (broadcast) -- instead of going back to L1/L2 for 3 KB per step.  A
+// wave with more distinct elements (thinly populated elements) takes further turns of the stage/solve
+// loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
 template <int ORDER, int DIM, typename IDX>
 __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
     i64 k, int kavail, i64 npoints, const IDX *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
@@ -472,7 +472,10 @@ __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
     constexpr int P = G::P;
     constexpr int kNodeDoubles = P * DIM;
     __shared__ int2 s_queue[kGllWaveQueue];
-    __shared__ double s_ctrl[2][kNodeDoubles];
+    // elements staged per turn: two at order 4 in 3-D (3 KB each; four measured slower: 7.9 vs 7.6 ms at cfg5's
+    // shape -- a tenth of the waves span more than two elements, every wave pays the LDS), more for small elements
+    constexpr int kStaged = kNodeDoubles <= 81 ? 4 : 2;
+    __shared__ double s_ctrl[kStaged][kNodeDoubles];
     const int lane = threadIdx.x;
     int held = 0;
     unsigned long long missing_total = 0;
@@ -508,22 +511,29 @@ __global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
 #pragma unroll
         for (int d = 0; d < DIM; ++d) best_xi[d] = 10e9;
         while (__any(pending)) {
-            // the (up to) two elements of this turn: the first pending lane's and the first other one
-            const unsigned long long pmask = __ballot(pending);
-            const i64 ea = __shfl(e, __ffsll((long long)pmask) - 1);
-            const unsigned long long omask = __ballot(pending && e != ea);
-            const i64 eb = omask ? __shfl(e, __ffsll((long long)omask) - 1) : ea;
-            for (int t = lane; t < kNodeDoubles; t += 64) {
-                s_ctrl[0][t] = gll_points[ea * (i64)kNodeDoubles + t];
-                s_ctrl[1][t] = gll_points[eb * (i64)kNodeDoubles + t];
+            // the (up to) kStaged elements of this turn: the first pending lane's, the first other one, ...
+            int which = -1;   // this lane's element among the staged ones (an offset into s_ctrl)
+            unsigned long long left = __ballot(pending);
+#pragma unroll
+            for (int m = 0; m < kStaged; ++m) {
+                if (left == 0) break;   // (wave-uniform)
+                const i64 em = __shfl(e, __ffsll((long long)left) - 1);
+                for (int t = lane; t < kNodeDoubles; t += 64) s_ctrl[m][t] = gll_points[em * (i64)kNodeDoubles + t];
+                const bool hit = pending && e == em;
+                if (hit) which = m * kNodeDoubles;
+                left &= ~__ballot(hit);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool mine = pending && (e == ea || e == eb);
+            const bool mine = which >= 0;
             if (mine) {
                 double xi[DIM];
-                G::inverse_transform(pnt, e == ea ? s_ctrl[0] : s_ctrl[1], xi);
+                // a per-lane OFFSET into the staged nodes: with a select between the arrays the compiler
+                // reads every node of all of them and picks the values lane by lane (750 v_cndmask_b32 and
+                // twice the LDS reads per Newton step at order 4 with two arrays)
+                asm volatile("" : "+v"(which));
+                G::inverse_transform(pnt, &s_ctrl[0][0] + which, xi);
                 bool isnan_any = false;
                 double worst = 0.0;
 #pragma unroll
