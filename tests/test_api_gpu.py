@@ -165,6 +165,35 @@ def test_unique_points_equal_numpy(dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["general", "box_faces", "many_long_runs", "lattice"])
+def test_unique_points_runs_of_equal_x(kind):
+    # one sort by x, then the runs of equal x: short ones (copies of shared nodes) in place, the few long ones (the
+    # faces of a box mesh) as a sub-sort, clouds that are mostly long runs by dim stable sorts -- every route against np.unique
+    from multimesh_amd.device import Context
+    rng = np.random.default_rng(5)
+    n = 150_000
+    pts = rng.uniform(size=(n, 3))
+    if kind == "box_faces":
+        pts[:9000, 0] = 0.0
+        pts[9000:14000, 0] = 1.0
+        pts[14000:14040, 0] = 0.5                           # a run just above the in-place limit
+        pts[:14040, 1] = np.round(pts[:14040, 1], 2)        # ties in y inside the long runs: z decides
+    elif kind == "many_long_runs":
+        pts[:, 0] = np.round(pts[:, 0] * 5000) / 5000       # 5001 values of x, ~30 rows each: some runs longer than the limit
+        pts[:60_000, 0] = np.round(pts[:60_000, 0] * 400) / 400   # ... and 401 values with 150 rows each
+    elif kind == "lattice":
+        g = np.arange(53, dtype=np.float64) / 52
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)[rng.permutation(53 ** 3)]
+    pts = np.concatenate([pts, pts[rng.integers(0, len(pts), size=len(pts) // 3)]])   # exact duplicates of whole rows
+    pts = np.ascontiguousarray(pts[rng.permutation(len(pts))])
+    ctx = Context(0)
+    uniq, inv = ctx.unique_points(pts)
+    ref_u, ref_inv = np.unique(pts, axis=0, return_inverse=True)
+    assert np.array_equal(uniq.numpy(), ref_u) and np.array_equal(inv.numpy(), ref_inv.reshape(-1))
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_unique_points_edge_cases():
     from multimesh_amd.device import Context
     ctx = Context(0)
