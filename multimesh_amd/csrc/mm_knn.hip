@@ -45,6 +45,12 @@ constexpr double kLevelRatio = 2.0;
 constexpr int kMaxLevels = 9;
 constexpr int kLevelCount[kMaxLevels - 1] = {15, 19, 38, 77, 154, 307, 614, 1229};   // ~9.6 x ratio^(l-1); 15: noise
 constexpr double kLevelShare = 0.02;   // of the sources, in the band of level-0 cell counts a level serves
+// The other end: when more than kSparseShare of the sources sit in level-0 cells with at most kSparseCount of them
+// (a cloud with a large region at half the average density or less: there the k = 20 ball outgrows the 3x3x3
+// block and the targets fall to the ring-search kernel), level 0 is rebuilt with cells of twice the volume (at
+// most twice over); the denser regions then reach their cell size one level further down.
+constexpr int kSparseCount = 5;
+constexpr double kSparseShare = 0.25;
 constexpr i64 kLevelMinSources = 4096;
 constexpr i64 kLevelMaxCells = (i64)1 << 27;
 constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a denser level above this home-cell count
@@ -133,11 +139,21 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
 }
 
 // total[b] += the counts of the cells holding more than kLevelCount[b] sources (density levels).
+// total[kMaxLevels - 1] += the counts of the cells holding at most kSparseCount sources, from every
+// 2^sample_shift-th workgroup only (an estimate that steers a heuristic: nearly every wave of a uniform cloud has
+// such a cell, and 17 k atomics on one address are 0.1 ms).
 __global__ __launch_bounds__(kBlock) void level_share_kernel(const int *__restrict__ counts, i64 ncells,
-                                                             unsigned long long *__restrict__ total)
+                                                             unsigned long long *__restrict__ total, int sample_shift)
 {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int v = c < ncells ? counts[c] : 0;
+    if ((blockIdx.x & ((1u << sample_shift) - 1u)) == 0) {
+        int w = v <= kSparseCount ? v : 0;
+        if (__any(w > 0)) {
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+            if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(total + (kMaxLevels - 1), (unsigned long long)w);
+        }
+    }
 #pragma unroll
     for (int b = 0; b < kMaxLevels - 1; ++b) {
         int w = v > kLevelCount[b] ? v : 0;
@@ -2476,7 +2492,8 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
 // read back (while the scan and the scatter are still queued, so a uniform cloud pays no idle time
 // for it) and *level_extra = the number of denser levels the cloud asks for.
 static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
-                       bool use_context_buffers, int level, int *level_extra, mm_knn_index **out)
+                       bool use_context_buffers, int level, int *level_extra, mm_knn_index **out,
+                       double *sparse_share = nullptr)
 {
     static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
     const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
@@ -2560,14 +2577,15 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            counts, (const int *)nullptr, (const int *)nullptr);
     const bool want_stat = level_extra != nullptr && nsrc >= kLevelMinSources && live > 0;
+    const int sample_shift = (ncells + kBlock - 1) / kBlock >= 1024 ? 4 : 0;   // (the sparse share: see level_share_kernel)
     if (level_extra) *level_extra = 0;
     if (want_stat) {
         i64 *stat = ctx->d_counters + kStatSlot;
-        e = hipMemsetAsync(stat, 0, (kMaxLevels - 1) * sizeof(i64), ctx->stream);
+        e = hipMemsetAsync(stat, 0, kMaxLevels * sizeof(i64), ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(level_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                               ctx->stream, counts, ncells, (unsigned long long *)stat);
-            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, (kMaxLevels - 1) * sizeof(i64), hipMemcpyDeviceToHost,
+                               ctx->stream, counts, ncells, (unsigned long long *)stat, sample_shift);
+            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, kMaxLevels * sizeof(i64), hipMemcpyDeviceToHost,
                                ctx->stream);
         }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
@@ -2603,8 +2621,11 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
             const double next = b + 1 < kMaxLevels - 1 ? (double)ctx->h_counters[kStatSlot + b + 1] : 0.0;
             if (above - next > kLevelShare * (double)nsrc) *level_extra |= 1 << b;
         }
+        const double sparse_count = (double)ctx->h_counters[kStatSlot + kMaxLevels - 1] * (double)(1 << sample_shift);
+        if (sparse_share) *sparse_share = sparse_count / (double)nsrc;
         if (getenv("MM_KNN_DEBUG")) {
-            fprintf(stderr, "[mm_knn] build: %lld cells; %% of the sources in cells above", (long long)ncells);
+            fprintf(stderr, "[mm_knn] build: %lld cells; %% of the sources in cells of at most %d: %.1f, above", (long long)ncells,
+                    kSparseCount, 100.0 * sparse_count / (double)nsrc);
             for (int b = 0; b < kMaxLevels - 1; ++b)
                 fprintf(stderr, " %d: %.1f", kLevelCount[b], 100.0 * ctx->h_counters[kStatSlot + b] / (double)nsrc);
             fprintf(stderr, " -> level mask 0x%x\n", *level_extra);
@@ -2653,9 +2674,18 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     if (const char *env = getenv("MM_KNN_LEVELS")) max_levels = atoi(env) < 1 ? 1 : (atoi(env) > kMaxLevels ? kMaxLevels : atoi(env));
     int extra = 0;
     mm_knn_index *head = nullptr;
-    int rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, 0,
-                         max_levels > 1 ? &extra : nullptr, &head);
-    if (rc != MM_OK) return rc;
+    static const double sparse_limit = getenv("MM_KNN_SPARSE_SHARE") ? atof(getenv("MM_KNN_SPARSE_SHARE")) : kSparseShare;
+    int rc = MM_OK;
+    for (int scale = 1;; scale *= 2) {
+        double sparse = 0.0;
+        rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, 0, max_levels > 1 ? &extra : nullptr,
+                         &head, &sparse);
+        if (rc != MM_OK) return rc;
+        if (scale >= 4 || !(sparse > sparse_limit)) break;
+        free_index(head);   // a large sparse region: cells of twice the volume
+        head = nullptr;
+        per_cell *= 2.0;
+    }
     mm_knn_index *tail = head;
     for (int l = 1; l < max_levels; ++l) {
         per_cell /= kLevelRatio;
