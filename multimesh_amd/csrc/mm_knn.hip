@@ -1863,7 +1863,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                                                             const double *__restrict__ tsorted, IDX *__restrict__ idx_out,
                                                             double *__restrict__ dist_out, int *__restrict__ fb_list,
                                                             int *__restrict__ fb_count, const int2 *__restrict__ items,
-                                                            int nslots, int Z, int per_item, int sorted_rows)
+                                                            int nslots, int Z, int per_item, int sorted_rows,
+                                                            int *__restrict__ down_list, int *__restrict__ down_count)
 {
     // sorted_rows: a target's row goes to its position in the cell-sorted order (the fused pipeline's locate
     // stage then walks the targets in that order: rows and coordinates stream, neighbours share elements) and
@@ -1980,12 +1981,19 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 #endif
         MM_STAMP(1);   // cell extents arrived, offsets computed
         if (total > kLaneTileCap) {
-            // too full for the tile (a locally much denser region): the item's targets go to the generic kernel
+            // too full for the tile (a locally much denser region): the item's targets go to the next density
+            // level when there is one (a grid with smaller cells there), else to the generic kernel
             int base = 0;
-            if (lane == 0) base = atomicAdd(fb_count, tn);
-            base = __shfl(base, 0);
-            for (int q = lane; q < tn; q += kWave)
-                fb_list[base + q] = sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+            if (down_list) {
+                if (lane == 0) base = atomicAdd(down_count, tn);
+                base = __shfl(base, 0);
+                for (int q = lane; q < tn; q += kWave) down_list[base + q] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+            } else {
+                if (lane == 0) base = atomicAdd(fb_count, tn);
+                base = __shfl(base, 0);
+                for (int q = lane; q < tn; q += kWave)
+                    fb_list[base + q] = sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+            }
             continue;
         }
         // ---- stage, step 1: every entry's position in the sorted array (the cells' owners know them) ...
@@ -2398,7 +2406,7 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
         hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
                            ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count,
-                           lane->items, (int)lane->max_items, lane->Z, per_item, lane->sorted_rows);
+                           lane->items, (int)lane->max_items, lane->Z, per_item, lane->sorted_rows, down_list, down_count);
         if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
         return;
     }
@@ -2768,11 +2776,15 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     static const char *force_kernel = getenv("MM_KNN_KERNEL");
     LaneWork lane_work;
     bool use_lane = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK && npts >= 2 * ix->ncells;
+    // with density levels: level 0 only (every target starts there; strips too full for the tile are passed
+    // down), and only for the short lists the lane kernel is best at
+    static const bool lane_level0 = !(getenv("MM_KNN_LANE_LEVEL0") && atoi(getenv("MM_KNN_LANE_LEVEL0")) == 0);
+    if (!force_kernel && lane_level0 && ix->fine && ix->dims[2] >= 6 && k <= 8 && npts >= 2 * ix->ncells) use_lane = true;
     if (force_kernel) use_lane = strcmp(force_kernel, "lane") == 0 && !ix->fine && ix->dims[2] >= 2 && k <= kLaneMaxK;
     // MM_KNN_FORCE_LIST: every target through the list-mode kernel (tests of that kernel only)
     const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;   // (read per call: a test sets it)
     if (force_list) use_lane = false;
-    const bool sorted_rows = use_lane && tsorted_out != nullptr && !getenv("MM_KNN_UNSORTED_ROWS");
+    const bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !getenv("MM_KNN_UNSORTED_ROWS");
     lane_work.sorted_rows = sorted_rows ? 1 : 0;
     if (use_lane) {
         static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
@@ -2847,7 +2859,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                            start, tsorted, list, list_count);
 #define MM_FAST(KK)                                                                                                  \
     launch_fast<KK, IDX>(ctx, l, gl, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count, down_list, \
-                         down_count, level == 0, strip_list, strip_count, use_lane ? &lane_work : nullptr)
+                         down_count, level == 0, strip_list, strip_count, use_lane && level == 0 ? &lane_work : nullptr)
         if (k <= 1) MM_FAST(1);
         else if (k <= 2) MM_FAST(2);
         else if (k <= 4) MM_FAST(4);
