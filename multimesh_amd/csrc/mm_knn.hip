@@ -1912,7 +1912,9 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             if (q < ntc && (unsigned)ix < (unsigned)g.nx && (unsigned)iy < (unsigned)g.ny) {
                 const int cellid = (ix * g.ny + iy) * g.nz + za + layer;
                 s0[b] = cell_start[cellid];
-                cnt[b] = cell_start[cellid + 1] - s0[b];
+                // (clamped: a cell of a clustered cloud can hold more than the 16 bits the packed prefix sums below
+                // give a running total -- one source too many for the tile is all the overflow test needs to see)
+                cnt[b] = min(cell_start[cellid + 1] - s0[b], kLaneTileCap + 1);
             }
         }
         int t0 = tstart[col * g.nz + cz0];

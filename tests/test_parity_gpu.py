@@ -711,6 +711,19 @@ def test_knn_two_densities_like_a_locally_refined_mesh(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 8])
+def test_knn_lane_kernel_next_to_a_cell_with_more_than_65535_sources(ctx, k):
+    # a clustered cloud: one level-0 cell holds 131 k sources.  The lane kernel (level 0 of a multi-level grid for
+    # k <= 8) packs two running cell counts into one 32-bit word; found by tools/fuzz_knn.py (seed 501, case 2017):
+    # the count wrapped, the tile looked as if it fitted, and targets near the cluster got far-away neighbours
+    rng = np.random.default_rng(17)
+    src = np.concatenate([rng.uniform(size=(40_000, 3)), 0.52 + 1e-3 * rng.normal(size=(2 * 65536 + 300, 3))])   # = 300 mod 2^16
+    q = np.concatenate([rng.uniform(-0.1, 1.1, size=(70_000, 3)), 0.52 + 0.05 * rng.normal(size=(20_000, 3))])
+    idx = ctx.knn_build(src).query(q, k).numpy()
+    assert np.array_equal(idx, O.knn_ckdtree(src, q, k, workers=-1)[0])
+
+
+@pytest.mark.gpu
 def test_knn_list_mode_one_wave_per_target(ctx, monkeypatch):
     # the kernel that serves the targets the fast kernels hand over (and the locate stage's lazily fetched full
     # lists), here given EVERY target: rings, pruning, the wave-wide merge, ties by index, pads, density levels
