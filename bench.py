@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the mesh-to-mesh interpolation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload metric|cfg2|cfg3|cfg4]
+    python bench.py --gpus N --steps K --warmup W [--workload metric|cfg2|cfg3|cfg4|cfg5] [--scaling strong|weak]
 
 With N > 1 and no WORLD_SIZE in the environment this process is only a launcher: it starts N
 fresh ranks (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
@@ -16,24 +16,36 @@ the interpolated field when N > 1).
 
 Workloads:
   metric  BASELINE.json's metric configuration: 10M -> 10M nodes (216^3 jittered hex meshes),
-          1 scalar field, k = 20.  Weak scaling: every rank interpolates its own 10M-node target
-          mesh (jitter seed 7 + rank) from the replicated source mesh.
+          1 scalar field, k = 20.
   cfg3    the same with the 3-component vector field;  cfg2: 1M -> 1M.
   cfg4    100.5M-node target mesh (465^3, seed 7) cut into 8 contiguous shards
           (``shard_bounds(465^3, 8, s)``, ~12.57M targets = a 58-plane slab each) over the replicated
           216^3 source.  Rank r interpolates shard r (8 ranks = the whole mesh; fewer ranks = the
           first N shards; 1 rank: shard ``--cfg4-shard``, default 0), so per-GPU work is fixed.
+  cfg5    order-4 GLL hexes: 43^3 source elements, targets = the unique GLL points of a 47^3-element
+          mesh (found on the device: mm_unique_points), fused mm_interpolate_gll, k = 20, tolerance 1.05
+          (reference components/interpolator.py:931-977, 1181-1233).  PARITY UNPINNED (salvus.fem absent).
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     HBM roofline of the dominant single kernel (algorithmic bytes / its measured duration),
-  "stages":       the same accounting for every stage, with the bytes the implementation really moves
-                  ("actual_bytes": HBM-unique, narrowed dtypes) beside SURVEY section 8(d)'s figure,
-  "gather_reapply": the stand-alone A9 gather on the operator of this very run (reference
-                  interpolator.py:724-740: operator cached, only the gather re-runs per field),
-  "allgather_ms": one blocking all-gather of the field, timed by itself (N > 1),
-  "cpu_baseline": the reference's CPU path timed on this box's host cores on a bounded sample.
+Scaling at N > 1 (reference interpolator.py:1239-1254 chunks ONE target set):
+  strong  (default for metric / cfg2 / cfg3 / cfg5) ONE target mesh; rank r takes rows
+          ``shard_bounds(N_targets, world, r)``; one all-gather reassembles the field, which is compared
+          WHOLE with a single-rank run.  The line also carries a weak-scaling measurement (`weak`)
+          and the replicated (Amdahl) share of a step: centroids + grid build run on every rank.
+  weak    every rank interpolates its own full-size target mesh (jitter seed 7 + rank); cfg4 is weak by
+          construction (one fixed-size shard per rank).
+
+Rank 0 prints ONE JSON line on stdout (everything else, RCCL's banner included, goes to stderr) with
+the contract fields plus
+  "roofline":      HBM roofline of the dominant single kernel, named as rocprofv3 names it,
+  "roofline_valu": the VALU-issue floor of the two dominant kernels (instruction counts by class from the
+                   committed counter passes x the measured issue cost of each class),
+  "stages":        the byte accounting for every stage (SURVEY 8(d)'s figure and the bytes really moved),
+  "gather_reapply": the stand-alone A9 gather on the operator of this very run,
+  "allgather":     the collective timed by itself + the whole-field comparison (N > 1),
+  "cpu_baseline":  the reference's CPU path timed on this box's host cores on a bounded sample.
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -53,6 +65,8 @@ from multimesh_amd.helpers import STAGES  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a device-to-device copy reaches ~5 TB/s (roofline.measured_copy_GBps)
 CFG4_SHARDS = 8
 LAZY_K = 8              # candidates the kNN stage delivers up front (mm_set_lazy_lists)
+N_SIMD = 256 * 4        # MI355X: 256 CUs x 4 SIMDs
+VERIFY_CHUNK = 16_000_000   # rows per single-rank call of the whole-field comparison
 
 
 def algorithmic_bytes(n_targets, n_elem, n_nodes, k, ncomp):
@@ -94,24 +108,74 @@ def actual_bytes(n_targets, n_elem, n_nodes, k, ncomp, fused_gather):
     }
 
 
-#: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline)
+def gll_bytes(n_targets, n_elem, P, dim, k, ncomp):
+    """SURVEY.md §8(d) for the GLL path: locate ~ point + k candidates + one element's control nodes + the
+    coefficient row; gather = element id + P coefficients + C * (P gathered + 1 written)."""
+    return {
+        "knn_query": n_targets * (8 * dim + 8 * k) + n_elem * 8 * dim,
+        "locate": n_targets * (8 * dim + 8 * k + 8 * P * dim + 8 + 8 * P),
+        "gather": n_targets * (8 + 8 * P + ncomp * (8 * P + 8)),
+    }
+
+
+#: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline), by the name
+#: rocprofv3 --kernel-trace prints for them (profiles/*_kernel_stats.csv)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
-KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "kNN tile kernel (see config.knn_kernel)",
-                   "locate_pass0": "locate_pass_kernel<true, int> (first pass)", "gather": "gather8_kernel<true>"}
+KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_lane_kernel<8, int>",
+                   "locate_pass0": "locate_pass_kernel<true, int, true>", "gather": "gather8_kernel<true>"}
+#: what the counters say limits each of them (DESIGN.md §4-5): the two big kernels sit on the vector-issue
+#: floor, the streaming ones on HBM
+BOUND_OF_STAGE = {"centroid": "hbm", "knn_cell": "valu", "locate_pass0": "valu", "gather": "hbm"}
+#: key of the kernel in profiles/*_knn_counters.json
+COUNTER_KEY = {"knn_cell": "knn_lane_kernel", "locate_pass0": "locate_pass_kernel"}
+
+
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def measured_traffic(kernel_stage):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
     FETCH_SIZE doubled for wide streaming reads as MI355X_MICROARCH.md prescribes); None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
+    f = _latest("*_pmc_traffic.json")
+    if not f:
         return None
     try:
-        data = json.load(open(files[-1]))
-        return data.get(kernel_stage, {}).get("hbm_bytes_per_launch")
+        return json.load(open(f)).get(kernel_stage, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def valu_floor(stage, ms, scale=1.0):
+    """VALU-issue floor of a kernel: wave-instructions per launch by class (profiles/*_knn_counters.json:
+    SQ_INSTS_VALU and its ADD/MUL/FMA_F32 sub-counters, collected on the metric workload) x the issue cost of
+    each class at saturation (profiles/*_valu_issue.json from tools/valu_issue.hip: the fp32 add/mul/fmac class
+    issues every ~2.4 cycles per SIMD, everything else -- min/max/med3, compares, three-operand and 64-bit
+    forms -- every ~4.4), spread over the chip's 1024 SIMDs at the measured clock.  `scale` rescales the counts
+    when the launch is not the metric workload's (targets ratio).  None when the profiles are absent."""
+    fc, fi = _latest("*_knn_counters.json"), _latest("*_valu_issue.json")
+    if not (fc and fi and stage in COUNTER_KEY):
+        return None
+    try:
+        c = json.load(open(fc)).get(COUNTER_KEY[stage], {})
+        issue = json.load(open(fi))
+        total = c["SQ_INSTS_VALU"] * scale
+        fast = sum(c.get(n, 0.0) for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")) * scale
+        have_mix = "SQ_INSTS_VALU_ADD_F32" in c
+        slow = total - fast
+        cyc = fast * issue["fast_class_cycles"] + slow * issue["slow_class_cycles"]
+        floor_ms = cyc / N_SIMD / (issue["clock_GHz"] * 1e9) * 1e3
+        return {"kernel": KERNEL_OF_STAGE[stage], "valu_wave_insts_per_launch": round(total),
+                "fast_class_insts": round(fast) if have_mix else None,
+                "issue_cycles": {"fast_class": issue["fast_class_cycles"], "slow_class": issue["slow_class_cycles"]},
+                "clock_GHz": issue["clock_GHz"], "floor_ms": round(floor_ms, 4), "ms": round(ms, 4),
+                "frac": round(floor_ms / ms, 4) if ms > 0 else None,
+                "source": [os.path.relpath(fc, ROOT), os.path.relpath(fi, ROOT)],
+                "note": "floor = (fast-class insts x fast cycles + the rest x slow cycles) / 1024 SIMDs / clock; "
+                        "counts from the committed counter passes of the metric workload, not re-measured in this run"}
+    except Exception as exc:   # a malformed profile must not break the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def cpu_baseline(pa, ca, pb, fields, k, sample_stride):
@@ -193,18 +257,25 @@ def hbm_copy_gbps(torch, dev, nbytes=1 << 31, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+WORKLOADS = sorted(list(synth.CONFIGS) + ["cfg5"])
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="metric", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--workload", default="metric", choices=WORKLOADS)
+    ap.add_argument("--scaling", default="auto", choices=("auto", "strong", "weak"),
+                    help="N > 1: strong = one target set sharded over the ranks (default except cfg4), weak = one full "
+                         "target set per rank")
     ap.add_argument("--n-src", type=int, default=0, help="override nodes per side of the source mesh")
     ap.add_argument("--n-tgt", type=int, default=0, help="override nodes per side of the target mesh")
     ap.add_argument("--ncomp", type=int, default=0)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--cfg4-shard", type=int, default=0, help="cfg4 at one rank: which of the 8 shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak-beside", action="store_true", help="strong scaling at N > 1: skip the weak-scaling side run")
     ap.add_argument("--cpu-sample-stride", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -218,15 +289,54 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(args, argv):
-    """Start ``args.gpus`` ranks as CHILD processes and return their exit code.  Nothing in this
-    process initialises the GPU (``torch.cuda.device_count()`` only counts devices), and nothing is
-    exec'ed over it: the ranks are fresh interpreters started by torch.distributed.run."""
-    import torch
+def count_gpus_without_runtime():
+    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs are GPUs; CPUs have simd_count 0):
+    nothing here loads the HIP runtime, so the launcher process never initialises a device.  None when the
+    count cannot be had (then the ranks themselves fail when a device is missing)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+                        break
+        visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+        if visible is not None and visible.strip() != "":
+            n = min(n, len([v for v in visible.split(",") if v.strip() != ""]))
+        return n
+    except OSError:
+        pass
+    # no KFD topology in sysfs (a container without the driver's sysfs tree): ask a CHILD process, which may
+    # initialise whatever it likes and is gone before the ranks start
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
 
+
+def under_profiler():
+    """A rocprofiler tool library is preloaded into this process (rocprofv3 -- python3 bench.py ...): its
+    library has initialised the GPU already, so starting ranks from here would be a launcher hop under it."""
+    env = os.environ
+    return any(k in env for k in ("ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES",
+                                  "ROCPROFILER_LIBRARY")) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
+def launch_ranks(args, argv):
+    """Start ``args.gpus`` ranks as CHILD processes and return their exit code.  Nothing in this process
+    touches the GPU runtime (devices are counted from sysfs), and nothing is exec'ed over it: the ranks are
+    fresh interpreters started by torch.distributed.run."""
     rehearse = os.environ.get("MM_BENCH_REHEARSE") == "1"    # ranks share GPU 0, gloo carries the collectives
-    have = torch.cuda.device_count()
-    if have < args.gpus and not rehearse:
+    if under_profiler():
+        print("bench.py: --gpus N > 1 starts its own ranks and must not run under a profiler; profile one rank "
+              "(rocprofv3 ... -- python3 bench.py --gpus 1 ...)", file=sys.stderr)
+        return 2
+    have = count_gpus_without_runtime()
+    if have is not None and have < args.gpus and not rehearse:
         print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -237,10 +347,65 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+class StdoutToStderr:
+    """Everything written to file descriptor 1 while this is active -- RCCL prints a version banner there
+    when a communicator is created -- goes to stderr; ``emit`` writes to the real stdout.  The contract is ONE
+    JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def emit(self, text):
+        os.write(self.real, (text + "\n").encode())
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.real, 1)
+        os.close(self.real)
+
+
 # ------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------
-def run_rank(args):
+class Dist:
+    """The process group of a run (or its single-process stand-in)."""
+
+    def __init__(self, torch, dist, dev, world, rehearse, use_dist):
+        self.torch, self.dist, self.dev, self.world, self.rehearse, self.use = torch, dist, dev, world, rehearse, use_dist
+        self.backend = ("gloo (REHEARSAL: ranks share GPU 0)" if rehearse else "nccl (RCCL)") if use_dist else None
+
+    def barrier(self):
+        if self.use:
+            self.dist.barrier()
+
+    def all_gather(self, t_all, t_out, async_op=False):
+        """The one collective of the path (SURVEY.md §8e): equal, padded blocks -> [world*chunk, C]."""
+        if self.rehearse:     # gloo has no device all-gather: staged through the host (control flow only)
+            parts = [self.torch.empty(t_out.shape, dtype=t_out.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, t_out.cpu())
+            t_all.copy_(self.torch.cat(parts))
+            return None
+        return self.dist.all_gather_into_tensor(t_all, t_out, async_op=async_op)
+
+    def all_max(self, x):
+        if not self.use:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.rehearse else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum_int(self, x):
+        if not self.use:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int64, device="cpu" if self.rehearse else self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+
+def init_rank(args):
     import torch
     import torch.distributed as dist
 
@@ -250,7 +415,7 @@ def run_rank(args):
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-        return 2
+        return None
     rehearse = os.environ.get("MM_BENCH_REHEARSE") == "1"
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
@@ -263,68 +428,99 @@ def run_rank(args):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    return torch, dist, rank, world, dev_index, dev, Dist(torch, dist, dev, world, rehearse, use_dist)
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
 
-    def all_gather(t_all, t_out, async_op=False):
-        """The one collective of the path (SURVEY.md §8e): equal, padded blocks -> [world*chunk, C]."""
-        if rehearse:     # gloo has no device all-gather: staged through the host (control flow only)
-            parts = [torch.empty(t_out.shape, dtype=t_out.dtype) for _ in range(world)]
-            dist.all_gather(parts, t_out.cpu())
-            t_all.copy_(torch.cat(parts))
-            return None
-        return dist.all_gather_into_tensor(t_all, t_out, async_op=async_op)
+def timed_steps(args, torch, D, step, drain):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides;
+    the MAX over ranks of the elapsed wall time."""
+    for _ in range(args.warmup):
+        step(False)
+    drain()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    drain()                            # every gather of the timed steps has completed ...
+    torch.cuda.synchronize()           # ... and so has everything else on the device
+    D.barrier()
+    return D.all_max(time.perf_counter() - t0)
 
+
+def run_rank(args, out):
+    init = init_rank(args)
+    if init is None:
+        return 2
+    if args.workload == "cfg5":
+        return run_rank_gll(args, out, *init)
+    return run_rank_hex8(args, out, *init)
+
+
+def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
+    use_dist, rehearse = D.use, D.rehearse
     cfg = dict(synth.CONFIGS[args.workload])
     n_src = args.n_src or cfg["n_src"]
     n_tgt = args.n_tgt or cfg["n_tgt"]
     ncomp = args.ncomp or cfg["ncomp"]
     k = args.k
+    sharded = args.workload == "cfg4"
+    scaling = args.scaling if args.scaling != "auto" else ("weak" if sharded else "strong")
+    if sharded and scaling == "strong":
+        if rank == 0:
+            print("bench.py: cfg4 is one fixed shard per rank (weak scaling by construction)", file=sys.stderr)
+        return 2
 
     # ---- synthetic inputs (host), then resident in HBM before any timing ----
     pa, ca = synth.hex_mesh(n_src, seed=1)
-    sharded = args.workload == "cfg4"
+    n_all = n_tgt ** 3
     if sharded:
         # rank r owns shard r of the 8 the 100.5M-node target mesh is cut into (never a cube of its own)
-        shard = rank if world > 1 else args.cfg4_shard
-        if not 0 <= shard < CFG4_SHARDS or world > CFG4_SHARDS:
+        if not 0 <= args.cfg4_shard < CFG4_SHARDS or world > CFG4_SHARDS:
             if rank == 0:
                 print("bench.py: cfg4 has 8 shards", file=sys.stderr)
             return 2
-        lo, hi = shard_bounds(n_tgt ** 3, CFG4_SHARDS, shard)
+
+        def bounds(r):
+            return shard_bounds(n_all, CFG4_SHARDS, r if world > 1 else args.cfg4_shard)
+
         def tgt_rows(r, a, b):
             """rows [a, b) of rank r's block of targets"""
-            base = shard_bounds(n_tgt ** 3, CFG4_SHARDS, r if world > 1 else args.cfg4_shard)[0]
-            return synth.hex_mesh_rows(n_tgt, base + a, base + b, seed=7)
+            return synth.hex_mesh_rows(n_tgt, bounds(r)[0] + a, bounds(r)[0] + b, seed=7)
 
-        pb = synth.hex_mesh_rows(n_tgt, lo, hi, seed=7)
-        chunk = -(-n_tgt ** 3 // CFG4_SHARDS)          # ceil: the last shard is 7 rows short, blocks are padded
-        target_desc = (f"shard {shard} of {CFG4_SHARDS} of the {n_tgt}^3 = {n_tgt ** 3}-node target mesh (rows {lo}..{hi}: "
-                       f"a {(hi - 1) // n_tgt ** 2 - lo // n_tgt ** 2 + 1}-plane slab), rank r <-> shard r")
+        chunk = -(-n_all // CFG4_SHARDS)          # ceil: the last shard is 7 rows short, blocks are padded
+        lo, hi = bounds(rank)
+        target_desc = (f"shard {rank if world > 1 else args.cfg4_shard} of {CFG4_SHARDS} of the {n_tgt}^3 = {n_all}-node target "
+                       f"mesh (rows {lo}..{hi}: a {(hi - 1) // n_tgt ** 2 - lo // n_tgt ** 2 + 1}-plane slab), rank r <-> shard r")
+    elif scaling == "strong":
+        def bounds(r):
+            return shard_bounds(n_all, world, r)
+
+        def tgt_rows(r, a, b):
+            return synth.hex_mesh_rows(n_tgt, bounds(r)[0] + a, bounds(r)[0] + b, seed=7)
+
+        chunk = -(-n_all // world)
+        lo, hi = bounds(rank)
+        target_desc = (f"ONE {n_tgt}^3 = {n_all}-node target mesh (jitter seed 7)" +
+                       (f", rank r takes rows shard_bounds({n_all}, {world}, r) (this rank: {lo}..{hi})" if world > 1 else ""))
     else:
+        def bounds(r):
+            return 0, n_all
+
         def tgt_rows(r, a, b):
             return synth.hex_mesh_rows(n_tgt, a, b, seed=7 + r)
 
-        pb, _ = synth.hex_mesh(n_tgt, seed=7 + rank)
-        chunk = pb.shape[0]
+        chunk = n_all
         target_desc = f"every rank its own {n_tgt}^3-node target mesh (jitter seed 7 + rank)"
+    n_rows = [bounds(r)[1] - bounds(r)[0] for r in (range(world) if world > 1 else [rank])]
+    n_local = bounds(rank)[1] - bounds(rank)[0]
+    total_targets = sum(n_rows)
+    pb = tgt_rows(rank, 0, n_local)
     fields = synth.vector_field(pa)[:ncomp]
     t_nodes = torch.from_numpy(pa).to(dev)
     t_conn = torch.from_numpy(ca).to(dev)
     t_pts = torch.from_numpy(pb).to(dev)
     t_fields = torch.from_numpy(fields).to(dev)
-    n_local = pb.shape[0]
-    # Two sets of output buffers: with more than one rank the all-gather of step s runs on RCCL's own
-    # stream while step s+1 computes into the other set (the gather only reads its own step's block).
-    nbuf = 2 if use_dist else 1
-    t_outs = [torch.zeros((chunk, ncomp), dtype=torch.float64, device=dev) for _ in range(nbuf)]
-    t_alls = [torch.empty((world * chunk, ncomp), dtype=torch.float64, device=dev) if use_dist else None
-              for _ in range(nbuf)]
-    t_out, t_all = t_outs[0], t_alls[0]
-    pending = [None] * nbuf
-    step_no = [0]
 
     from multimesh_amd.device import Context
 
@@ -332,100 +528,102 @@ def run_rank(args):
     ctx = Context(dev_index, stream=stream)
     ctx.set_profiling(True)
 
-    stage_ms = {s: 0.0 for s in STAGES}
-    nfailed_total = 0
+    def make_run(points, n_loc, blk):
+        """step / drain closures of one measurement over `points` (this rank's targets) with blocks of `blk`
+        rows in the all-gather.  Two sets of output buffers: with more than one rank the all-gather of step s
+        runs on RCCL's own stream while step s+1 computes into the other set."""
+        nbuf = 2 if use_dist else 1
+        st = {"outs": [torch.zeros((blk, ncomp), dtype=torch.float64, device=dev) for _ in range(nbuf)],
+              "alls": [torch.empty((world * blk, ncomp), dtype=torch.float64, device=dev) if use_dist else None
+                       for _ in range(nbuf)],
+              "pending": [None] * nbuf, "n": 0, "stage_ms": {s: 0.0 for s in STAGES}, "nfailed": 0, "last": 0}
 
-    def step(record):
-        nonlocal nfailed_total, t_out, t_all
-        b = step_no[0] % nbuf
-        step_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()          # the gather that last read this buffer set (two steps ago)
-            pending[b] = None
-        t_out, t_all = t_outs[b], t_alls[b]
-        _, nf = ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, out=t_out[:n_local])
-        if use_dist:
-            # asynchronous: the gather overlaps the next step's kernels
-            pending[b] = all_gather(t_all, t_out, async_op=True)
-        if record:
-            nfailed_total += nf
-            for s, v in ctx.last_timings().items():
-                stage_ms[s] += v
+        def step(record):
+            b = st["n"] % nbuf
+            st["n"] += 1
+            st["last"] = b
+            if st["pending"][b] is not None:
+                st["pending"][b].wait()          # the gather that last read this buffer set (two steps ago)
+                st["pending"][b] = None
+            _, nf = ctx.interpolate_hex8(t_nodes, t_conn, points, t_fields, nelem_to_search=k, out=st["outs"][b][:n_loc])
+            if use_dist:
+                # asynchronous: the gather overlaps the next step's kernels
+                st["pending"][b] = D.all_gather(st["alls"][b], st["outs"][b], async_op=True)
+            if record:
+                st["nfailed"] += nf
+                for s, v in ctx.last_timings().items():
+                    st["stage_ms"][s] += v
 
-    def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        def drain():
+            for b in range(nbuf):
+                if st["pending"][b] is not None:
+                    st["pending"][b].wait()
+                    st["pending"][b] = None
 
-    for _ in range(args.warmup):
-        step(False)
-    drain()
+        return st, step, drain
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    drain()                            # every gather of the timed steps has completed ...
-    torch.cuda.synchronize()           # ... and so has everything else on the device
-    barrier()
-    elapsed = time.perf_counter() - t0
+    st, step, drain = make_run(t_pts, n_local, chunk)
+    elapsed = timed_steps(args, torch, D, step, drain)
+    stage_ms = st["stage_ms"]
+    nfailed_total = D.all_sum_int(st["nfailed"])
+    t_out, t_all = st["outs"][st["last"]], st["alls"][st["last"]]
 
-    def all_max(x):
-        if not use_dist:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    elapsed = all_max(elapsed)
-    if use_dist:
-        nf_t = torch.tensor([nfailed_total], dtype=torch.int64, device="cpu" if rehearse else dev)
-        dist.all_reduce(nf_t)
-        nfailed_total = int(nf_t.item())
-
-    # ---- the collective by itself: one extra step with a BLOCKING all-gather, timed on the stream ----
+    # ---- the collective by itself: a BLOCKING all-gather, timed on the stream; then the WHOLE gathered field
+    # against what one rank computes alone ----
     allgather = None
     if use_dist:
         ms = []
         for _ in range(3):
             torch.cuda.synchronize()
-            barrier()
+            D.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            all_gather(t_all, t_out)
+            D.all_gather(t_all, t_out)
             e1.record()
             e1.synchronize()
             ms.append(e0.elapsed_time(e1))
-        ag_ms = all_max(sorted(ms)[1])
+        ag_ms = D.all_max(sorted(ms)[1])
         nbytes_in = (world - 1) * chunk * ncomp * 8
-        allgather = {"ms": round(ag_ms, 4), "bytes_received_per_gpu": nbytes_in,
-                     "GBps_per_gpu": round(nbytes_in / (ag_ms * 1e-3) / 1e9, 1) if ag_ms > 0 else None,
+        allgather = {"backend": D.backend, "ms": round(ag_ms, 4), "bytes_received_per_gpu": nbytes_in,
+                     "GBps_per_gpu": round(nbytes_in / (ag_ms * 1e-3) / 1e9, 1) if ag_ms > 0 and nbytes_in else None,
                      "note": "median of 3 blocking all_gather_into_tensor calls (max over ranks); in the timed steps "
                              "the gather is asynchronous and overlaps the next step's kernels"}
-        # the gathered field = what one rank computes alone: rank 0 re-interpolates a sample of the LAST
-        # rank's block on its own GPU and compares bit for bit
         if rank == 0:
-            last = world - 1
-            n_last = (shard_bounds(n_tgt ** 3, CFG4_SHARDS, last)[1] - shard_bounds(n_tgt ** 3, CFG4_SHARDS, last)[0]
-                      if sharded else chunk)
-            ns = min(200_000, n_last)
-            sample = torch.from_numpy(tgt_rows(last, n_last - ns, n_last)).to(dev)
-            ref, _ = ctx.interpolate_hex8(t_nodes, t_conn, sample, t_fields, nelem_to_search=k)
-            ref = torch.from_numpy(ref.numpy()).to(dev)
-            got = t_all[last * chunk + n_last - ns:last * chunk + n_last]
-            allgather["gathered_equals_single_rank_on_sample"] = bool(torch.equal(got, ref))
-            allgather["sample"] = f"last {ns} targets of rank {last}'s block"
-            assert torch.equal(t_all[:n_local], t_out[:n_local]), "all-gather did not return this rank's block"
+            # rank 0 re-interpolates EVERY rank's block on its own GPU, alone, and compares the gathered rows bit
+            # for bit (strong scaling: that is the 1-GPU result of the one target set, row for row)
+            t0 = time.perf_counter()
+            equal, rows = True, 0
+            ref = torch.empty((min(VERIFY_CHUNK, max(n_rows)), ncomp), dtype=torch.float64, device=dev)
+            for r in range(world):
+                for a in range(0, n_rows[r], VERIFY_CHUNK):
+                    b = min(a + VERIFY_CHUNK, n_rows[r])
+                    pts_r = t_pts[a:b] if r == rank else torch.from_numpy(tgt_rows(r, a, b)).to(dev)
+                    ctx.interpolate_hex8(t_nodes, t_conn, pts_r, t_fields, nelem_to_search=k, out=ref[:b - a])
+                    equal = equal and bool(torch.equal(ref[:b - a], t_all[r * chunk + a:r * chunk + b]))
+                    rows += b - a
+                    del pts_r
+            allgather["gathered_equals_single_rank"] = equal
+            allgather["rows_compared"] = rows
+            allgather["compare_s"] = round(time.perf_counter() - t0, 2)
+            del ref
+        D.barrier()
+
+    # ---- strong scaling: the weak-scaling figure beside it (every rank a full target mesh of its own) ----
+    weak = None
+    if use_dist and scaling == "strong" and world > 1 and not args.no_weak_beside:
+        pw = torch.from_numpy(synth.hex_mesh_rows(n_tgt, 0, n_all, seed=7 + rank)).to(dev)
+        wargs = argparse.Namespace(steps=min(args.steps, 5), warmup=min(args.warmup, 2))
+        stw, stepw, drainw = make_run(pw, n_all, n_all)
+        el = timed_steps(wargs, torch, D, stepw, drainw)
+        weak = {"value": n_all * world * wargs.steps / el, "unit": "points/s", "ms_per_step": el / wargs.steps * 1e3,
+                "steps": wargs.steps, "targets_per_gpu": n_all,
+                "note": "every rank its own full target mesh (jitter seed 7 + rank), same collective"}
+        del pw, stw, stepw, drainw
 
     rc = 0
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = elapsed / steps * 1e3
-        total_targets = n_local * world if not sharded else sum(
-            shard_bounds(n_tgt ** 3, CFG4_SHARDS, r)[1] - shard_bounds(n_tgt ** 3, CFG4_SHARDS, r)[0]
-            for r in (range(world) if world > 1 else [args.cfg4_shard]))
         value = total_targets * steps / elapsed
         n_elem, n_nodes = ca.shape[0], pa.shape[0]
         fused = stage_ms["gather"] == 0.0
@@ -461,43 +659,60 @@ def run_rank(args):
             stages[s] = account(ms, abytes[s], rbytes[s])
         dominant = max(SINGLE_KERNEL_STAGES, key=lambda s: stage_ms[s])
         d = stages[dominant]
-        roofline = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dominant], "stage": dominant,
+        knn_kernel = os.environ.get("MM_KNN_KERNEL", "lane")
+        roofline = {"bound": "hbm", "limited_by": BOUND_OF_STAGE[dominant],
+                    "kernel": KERNEL_OF_STAGE[dominant] if (dominant != "knn_cell" or knn_kernel == "lane")
+                    else f"knn_{knn_kernel}_kernel", "stage": dominant,
                     "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": d["frac"], "ms": d["ms"], "algorithmic_bytes": abytes[dominant],
                     "actual_bytes": rbytes[dominant], "frac_actual_bytes": d["frac_actual"],
                     "traffic": measured_traffic(dominant),
-                    "timing": "hipEvents on the context's stream around this kernel's launches, averaged over the timed steps"}
+                    "timing": "hipEvents on the context's stream around this kernel's launches, averaged over the timed steps",
+                    "note": "priced against the HBM roofline as SURVEY 8(d) asks (`bound`); `limited_by` is what the "
+                            "counters say actually limits the kernel -- for the kNN and locate kernels the vector-issue "
+                            "rate, quantified in roofline_valu"}
+        scale = n_local / 10_077_696.0      # the counter passes were taken on the metric workload
+        roofline_valu = {s: valu_floor(s, stages[s]["ms"], scale) for s in ("knn_cell", "locate_pass0")
+                         if stages[s].get("ms")}
         e2e_bytes = 952 + 72 * (ncomp - 1)          # 184 + 568 + 200 at C = 1, k = 20 (+72 per component)
         e2e_bytes += 8 * (k - 20) * 2
+        replicated_ms = stages["centroid"]["ms"] + stages["knn_build"]["ms"]
         line = {
             "metric": "interpolated points/sec, 10M->10M 3D mesh, 1 scalar field",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: hex8 3D {n_nodes} source nodes -> {n_local} targets per GPU (n_src={n_src}, "
-                                   f"n_tgt={n_tgt} per side, jittered unit cube), {ncomp} field component(s), k={k}; targets: "
-                                   + target_desc,
+            "config": {"workload": f"{args.workload}: hex8 3D {n_nodes} source nodes -> {total_targets} targets in all, "
+                                   f"{n_local} on rank 0 (n_src={n_src}, n_tgt={n_tgt} per side, jittered unit cube), "
+                                   f"{ncomp} field component(s), k={k}; targets: " + target_desc,
                        "source_nodes": n_nodes, "source_elements": n_elem, "targets_per_gpu": n_local,
                        "targets_total": total_targets,
                        "candidate_lists": f"evaluated lazily: the {LAZY_K} nearest centroids up front, the full "
                                           f"k={k} list only for targets that exhaust them; every output is "
                                           "bit-identical to the eager evaluation (mm_set_lazy_lists(0))",
-                       "knn_kernel": os.environ.get("MM_KNN_KERNEL", "default"),
-                       "parallelism": (f"targets sharded x{world}, source replicated, 1 all-gather per step (asynchronous: "
-                                       "overlaps the next step's kernels)" + (" [REHEARSAL: ranks share GPU 0, gloo]" if rehearse else ""))
-                       if world > 1 else "single GPU"},
+                       "knn_kernel": knn_kernel,
+                       "parallelism": (f"{scaling} scaling: targets sharded x{world}, source replicated, 1 all-gather per "
+                                       f"step over {D.backend} (asynchronous: overlaps the next step's kernels)")
+                       if use_dist else "single GPU"},
             "nfailed": nfailed_total,
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
             "roofline_end_to_end": {"algorithmic_bytes_per_target": e2e_bytes,
                                     "achieved_GBps_per_gpu": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "replicated_per_rank": {"ms": round(replicated_ms, 4), "share_of_step": round(replicated_ms / ms_per_step, 4),
+                                    "note": "centroids + search-grid build of the replicated source mesh run on every rank "
+                                            "whatever its share of the targets: the Amdahl term of strong scaling "
+                                            "(rank 0's stage timers)"},
             "stages": stages,
         }
         if allgather:
             line["allgather_ms"] = allgather["ms"]
             line["allgather"] = allgather
-            if allgather.get("gathered_equals_single_rank_on_sample") is False:
+            if allgather.get("gathered_equals_single_rank") is False:
                 rc = 1
+        if weak:
+            line["weak"] = weak
         roofline["measured_copy_GBps"] = round(hbm_copy_gbps(torch, dev), 1)
 
         # ---- stand-alone A9: the operator of THIS run re-applied to the field (the stored_array pattern) ----
@@ -547,11 +762,189 @@ def run_rank(args):
             line["parity_vs_cpu_sample"] = bool(np.array_equal(got, vals_c))
             if not line["parity_vs_cpu_sample"]:
                 rc = 1
-        print(json.dumps(line), flush=True)
+        out.emit(json.dumps(line))
 
     ctx.close()
     if use_dist:
-        barrier()
+        D.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------
+# cfg5: order-4 GLL hexes (reference components/interpolator.py:931-977)
+# ------------------------------------------------------------------------------------------
+def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
+    """cfg5 under the same contract: a step = device np.unique of the element-nodal target points (A11) +
+    the fused GLL path mm_interpolate_gll (centroids, grid, kNN, Newton location on the 125-node map, weighted
+    sum) over this rank's share of the unique points (+ the all-gather)."""
+    order, dim = 4, 3
+    ne_src = (args.n_src or 44) - 1
+    ne_tgt = (args.n_tgt or 48) - 1
+    k = args.k
+    ncomp = args.ncomp or 1
+    P = (order + 1) ** dim
+    scaling = "strong" if args.scaling in ("auto", "strong") else "weak"
+    src = synth.gll_mesh(ne_src + 1, order, seed=1)                       # [E, 125, 3]
+    tgt_en = synth.gll_mesh(ne_tgt + 1, order, seed=7).reshape(-1, dim)   # element-nodal target points
+    fields = np.stack([f(src.reshape(-1, dim)).reshape(src.shape[:2])
+                       for f in (synth.field_smooth, synth.field_linear, synth.field_xyz)][:ncomp])
+    from multimesh_amd.device import Context
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = Context(dev_index, stream=stream)
+    ctx.set_profiling(True)
+    t_src = torch.from_numpy(src).to(dev)
+    t_en = torch.from_numpy(tgt_en).to(dev)
+    t_fields = torch.from_numpy(fields).to(dev)
+    # the unique set once, to size the buffers (the timed steps recompute it into caller-owned buffers)
+    d_u, d_inv = ctx.unique_points(t_en)
+    t_ubuf = torch.empty(tgt_en.shape, dtype=torch.float64, device=dev)
+    t_ibuf = torch.empty((tgt_en.shape[0],), dtype=torch.int64, device=dev)
+    n_unique = d_u.shape[0]
+    if scaling == "strong":
+        lo, hi = shard_bounds(n_unique, world, rank)
+        chunk = -(-n_unique // world)
+        n_rows = [shard_bounds(n_unique, world, r)[1] - shard_bounds(n_unique, world, r)[0] for r in range(world)]
+    else:
+        lo, hi, chunk, n_rows = 0, n_unique, n_unique, [n_unique] * world
+    n_local = hi - lo
+    nbuf = 2 if D.use else 1
+    outs = [torch.zeros((chunk, ncomp), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    alls = [torch.empty((world * chunk, ncomp), dtype=torch.float64, device=dev) if D.use else None for _ in range(nbuf)]
+    st = {"n": 0, "pending": [None] * nbuf, "unique_ms": 0.0, "stage_ms": {s: 0.0 for s in STAGES}, "missing": 0, "last": 0}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def step(record):
+        b = st["n"] % nbuf
+        st["n"] += 1
+        st["last"] = b
+        if st["pending"][b] is not None:
+            st["pending"][b].wait()
+            st["pending"][b] = None
+        ev0.record()
+        u, inv = ctx.unique_points(t_en, unique_out=t_ubuf, inverse_out=t_ibuf)   # A11 on the device
+        ev1.record()
+        _, miss = ctx.interpolate_gll(order, t_src, u.rows(lo, hi), t_fields, nelem_to_search=k, tolerance=1.05,
+                                      out=outs[b][:n_local])
+        if D.use:
+            st["pending"][b] = D.all_gather(alls[b], outs[b], async_op=True)
+        if record:
+            st["missing"] += miss
+            st["unique_ms"] += ev0.elapsed_time(ev1)
+            for s, v in ctx.last_timings().items():
+                st["stage_ms"][s] += v
+
+    def drain():
+        for b in range(nbuf):
+            if st["pending"][b] is not None:
+                st["pending"][b].wait()
+                st["pending"][b] = None
+
+    elapsed = timed_steps(args, torch, D, step, drain)
+    missing = D.all_sum_int(st["missing"])
+    t_out = outs[st["last"]]
+    allgather = None
+    if D.use:
+        t_all = alls[st["last"]]
+        torch.cuda.synchronize()
+        D.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        D.all_gather(t_all, t_out)
+        e1.record()
+        e1.synchronize()
+        allgather = {"backend": D.backend, "ms": round(D.all_max(e0.elapsed_time(e1)), 4)}
+        if rank == 0:
+            ref = torch.empty((max(n_rows), ncomp), dtype=torch.float64, device=dev)
+            equal = True
+            for r in range(world):
+                a, b = shard_bounds(n_unique, world, r) if scaling == "strong" else (0, n_unique)
+                ctx.interpolate_gll(order, t_src, d_u.rows(a, b), t_fields, nelem_to_search=k, tolerance=1.05, out=ref[:b - a])
+                equal = equal and bool(torch.equal(ref[:b - a], t_all[r * chunk:r * chunk + b - a]))
+            allgather["gathered_equals_single_rank"] = equal
+            allgather["rows_compared"] = sum(n_rows)
+        D.barrier()
+
+    rc = 0
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed / steps * 1e3
+        total = sum(n_rows) if world > 1 else n_local
+        value = total * steps / elapsed
+        sm = {s: v / steps for s, v in st["stage_ms"].items()}
+        gb = gll_bytes(n_local, src.shape[0], P, dim, k, ncomp)
+        loc_ms = sm["locate"]
+        # the fused entry forms the weighted sum where a target is accepted: the locate stage carries the gather's bytes
+        alg = gb["locate"] + gb["gather"]
+        roofline = {"bound": "hbm", "limited_by": "valu (fp64 Newton on the 125-node map)",
+                    "kernel": "locate_gll_pass_kernel<4, 3, ...> (all passes of the stage)", "stage": "locate",
+                    "achieved": round(alg / (loc_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(alg / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "ms": round(loc_ms, 4),
+                    "algorithmic_bytes": alg, "traffic": None,
+                    "note": "SURVEY 8(d) GLL bytes: locate 24 + 8k + 3000 + 8 + 1000 and gather 8 + 1000 + 1008 C per target; "
+                            "the stage is bound by fp64 vector issue (~2.1 k fp64 operations per Newton step), see DESIGN.md"}
+        line = {
+            "metric": "interpolated points/sec, order-4 GLL hex mesh (cfg5), 1 scalar field",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg5: order-4 GLL hexes, {src.shape[0]} source elements ({ne_src}^3, {src.shape[0] * P} "
+                                   f"element-nodal points) -> the {n_unique} unique GLL points of a {ne_tgt}^3-element target mesh "
+                                   f"({tgt_en.shape[0]} element-nodal points), {ncomp} field component(s), k={k}, tolerance 1.05, "
+                                   "snap_to_nearest off; a step = device np.unique of the target points + mm_interpolate_gll",
+                       "parity": "UNPINNED: the reference's GLL numerics live in the absent salvus.fem; checked against this "
+                                 "repository's own CPU restatement (oracle/mm_oracle.c) only",
+                       "source_elements": int(src.shape[0]), "targets_per_gpu": n_local, "targets_total": total,
+                       "parallelism": (f"{scaling} scaling: unique targets sharded x{world}, source replicated, 1 all-gather "
+                                       f"per step over {D.backend}") if D.use else "single GPU"},
+            "nmissing": missing,
+            "roofline": roofline,
+            "stages": {"unique_points": {"ms": round(st["unique_ms"] / steps, 4),
+                                         "note": "mm_unique_points over all element-nodal target points (replicated on every rank)"},
+                       **{s: {"ms": round(v, 4)} for s, v in sm.items() if v > 0}},
+        }
+        if allgather:
+            line["allgather_ms"] = allgather["ms"]
+            line["allgather"] = allgather
+            if allgather.get("gathered_equals_single_rank") is False:
+                rc = 1
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle's restatement of the same loop on a bounded sample ("port": salvus.fem is absent)
+            from oracle import oracle as O
+            from scipy.spatial import cKDTree
+
+            stride = args.cpu_sample_stride or max(1, n_local // 60_000)
+            uniq = d_u.numpy()
+            sample = np.ascontiguousarray(uniq[::stride])
+            t0 = time.perf_counter()
+            cen = src.mean(axis=1)
+            tree = cKDTree(cen, balanced_tree=False)
+            t_build = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            _, nn = tree.query(sample, k=k)
+            t_query = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            elem_c, co_c, miss_c = O.locate_gll(order, nn, src, sample, 1.05, False)
+            t_loc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            vals_c = O.gather_elem(fields, elem_c, co_c)
+            t_g = time.perf_counter() - t0
+            t_full = t_build + (t_query + t_loc + t_g) / len(sample) * n_local
+            line["cpu_baseline"] = {"value": n_local / t_full, "unit": "points/s", "cores": 1, "kind": "port",
+                                    "sample": (f"EXTRAPOLATED from every {stride}th unique target ({len(sample)} points: cKDTree query "
+                                               f"{t_query:.2f}s, oracle mmo_locate_gll {t_loc:.2f}s, gather {t_g:.3f}s; tree build "
+                                               f"{t_build:.2f}s); np.unique of the element-nodal points not included; the reference "
+                                               "itself runs a Python loop around salvus.fem here and cannot be timed")}
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            got = t_out[:n_local].cpu().numpy()[::stride]
+            line["parity_vs_cpu_sample"] = bool(np.array_equal(got, vals_c))
+            if not line["parity_vs_cpu_sample"]:
+                rc = 1
+        out.emit(json.dumps(line))
+    ctx.close()
+    if D.use:
+        D.barrier()
         dist.destroy_process_group()
     return rc
 
@@ -560,7 +953,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
-    return run_rank(args)
+    with StdoutToStderr() as out:
+        return run_rank(args, out)
 
 
 if __name__ == "__main__":

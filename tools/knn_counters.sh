@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ / TCP / TCC / LDS counters of the bench's kernels (run on the GPU box): one rocprofv3 pass per
+# SQ / TCP / TCC / LDS counters of the bench's kernels (run on the GPU box; the VALU instruction classes of
+# bench.py's roofline_valu come from the SQ_INSTS_VALU_* group): one rocprofv3 pass per
 # counter group, each with --kernel-trace only, summarised per kernel into $1 (default
 # gpurun_out/counters/knn_counters.json) by tools/make_counter_profile.py.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -13,6 +14,7 @@ for group in \
   "SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+  "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT" \
   "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $group --output-format csv -d $O/pass$i -o p -- python3 $ARGS > $O/pass$i.log 2>&1 \
