@@ -914,7 +914,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
             from oracle import oracle as O
             from scipy.spatial import cKDTree
 
-            stride = args.cpu_sample_stride or max(1, n_local // 60_000)
+            stride = args.cpu_sample_stride or max(1, n_local // 2_400_000)   # ~10-15 s of single-threaded CPU work
             uniq = d_u.numpy()
             sample = np.ascontiguousarray(uniq[::stride])
             t0 = time.perf_counter()
