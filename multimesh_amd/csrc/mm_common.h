@@ -54,6 +54,12 @@ enum mm_buffer_slot {
     MM_BUF_H_POINTS,
     MM_BUF_H_FIELDS,
     MM_BUF_H_OUT,
+    MM_BUF_L_NN,                          // device copies of the LEGACY symbols' host arrays (centroid, triLinearInterpolator):
+    MM_BUF_L_CONN,                        //   grow-only like the rest, so a loop of calls (reference scripts/cli.py:183-195
+    MM_BUF_L_ENC,                         //   calls triLinearInterpolator once per GLL point of the element: 125 times)
+    MM_BUF_L_NODES,                       //   allocates once
+    MM_BUF_L_W,
+    MM_BUF_L_PTS,
     MM_BUF_LEVELS,                        // density levels of the kNN grid: {cell_start, sorted_xyz} per level
     MM_BUF_COUNT = MM_BUF_LEVELS + 2 * 8
 };

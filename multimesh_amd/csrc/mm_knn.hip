@@ -1786,6 +1786,10 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
 // the whole chip busy --, and XCD x takes the x-th eighth of the list (contiguous in space: its L2 sees
 // each source ~once).
 constexpr int kLaneTileCap = 768;      // sources per tile: (7 + 2) layers x 9 columns x ~8 = 648, + 4.7 sigma (Poisson)
+constexpr int kLaneTrips = kLaneTileCap / 64;   // staging trips: every lane holds its share of the WHOLE tile in registers
+constexpr int kLaneThin = 6;           // thin layers per cell layer (the tile is ordered by them, see the kernel's header)
+constexpr int kLaneWin = 5;            // half-width of a target's window in thin layers (first attempt; retried with kLaneThin): 5/6 of a cell edge
+constexpr int kLaneThinMax = 64;       // thin layers per tile: one lane each in the prefix sum
 constexpr int kLaneUnroll = 8;
 constexpr int kLanePad = 16;           // far-away entries behind the tile (a window read may run past it by < 12 entries)
 constexpr int kLaneZ = 7;              // cells per strip: ~57 targets per round of 64 lanes at 8 targets per cell
@@ -1864,7 +1868,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                                                             double *__restrict__ dist_out, int *__restrict__ fb_list,
                                                             int *__restrict__ fb_count, const int2 *__restrict__ items,
                                                             int nslots, int Z, int per_item, int sorted_rows,
-                                                            int *__restrict__ down_list, int *__restrict__ down_count)
+                                                            int *__restrict__ down_list, int *__restrict__ down_count,
+                                                            int T, int W)
 {
     // sorted_rows: a target's row goes to its position in the cell-sorted order (the fused pipeline's locate
     // stage then walks the targets in that order: rows and coordinates stream, neighbours share elements) and
@@ -1873,9 +1878,11 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
     constexpr int NE = K + 1;       // of which the first K + 1 get exact distances
     static_assert(K >= 1 && NE <= 32, "rank masks are 32 bits");
     constexpr bool kRowsInLds = K > 8;   // short rows are put in rank order in registers (no LDS: one more wave per SIMD)
+    constexpr bool kRetry = K <= 8;      // narrow windows first (the launcher passes W = T for the long lists)
     constexpr double kU = 0x1p-24;
     __shared__ float4 tile[kLaneTileCap + kLanePad];   // {x, y, z, position in the sorted array (bits; -1: padding)}
-    __shared__ int s_layer[kLaneZMax + 3];
+    __shared__ int s_hist[kLaneThinMax];       // entries per thin layer (ranks are handed out by the atomic)
+    __shared__ int s_thin[kLaneThinMax + 1];   // first entry of every thin layer; [NL ...] = the tile's length
     __shared__ int s_row[kRowsInLds ? kWave : 1][K | 1];   // long rows in rank order (odd stride: lanes on distinct banks)
 
     const int lane = threadIdx.x;
@@ -1886,12 +1893,12 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 #endif
     const int nstrips = (g.nz + Z - 1) / Z;
     const float4 far_entry = make_float4(kLaneFar, kLaneFar, kLaneFar, __int_as_float(-1));
-    bool staged_before = false;
-    for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {   // (one slot per workgroup by default)
-        const int2 item = items[slot];
-        if (item.x < 0) continue;
-        if (staged_before) wave_sync();   // the previous item's tile and rows are done with
-        staged_before = true;
+    {
+        // ONE work item per workgroup (the grid is the slot count): no loop around the item, so nothing the early
+        // phases need -- pointers, extents -- has to stay in scalar registers for a next trip
+        if ((int)blockIdx.x >= nslots) return;
+        const int2 item = items[blockIdx.x];
+        if (item.x < 0) return;
 #ifdef MM_LANE_STAMPS
         asm volatile("" ::"s"(item.x));
 #endif
@@ -1934,55 +1941,27 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             npz = zw.x;
             npw = zw.y;
         }
-        // ---- tile offsets: prefix sum over the cells in (layer, column) order ...
-        int off[2], total;
+        // ---- natural tile offsets: prefix sum over the cells in (layer, column) order
+        int nat[2], nat_total;
         {
-            // (both prefix sums in one word -- a tile holds < 2^16 sources --: six dependent shuffles instead of twelve)
-            int packed = cnt[0] | (cnt[1] << 16);
+            // (both prefix sums in one word -- a tile holds < 2^16 sources and the counts are clamped --: six dependent
+            // shuffles instead of twelve; unsigned, so that the upper sum may use all of its 16 bits)
+            unsigned packed = (unsigned)cnt[0] | ((unsigned)cnt[1] << 16);
             for (int d = 1; d < kWave; d <<= 1) {
-                const int a = __shfl_up(packed, d);
+                const unsigned a = (unsigned)__shfl_up((int)packed, d);
                 if (lane >= d) packed += a;
             }
-            const int incl0 = packed & 0xffff, incl1 = packed >> 16;
+            const int incl0 = (int)(packed & 0xffffu), incl1 = (int)(packed >> 16);
             const int tot0 = __builtin_amdgcn_readlane(incl0, kWave - 1);
-            const int nat_total = tot0 + __builtin_amdgcn_readlane(incl1, kWave - 1);
-            const int nat0 = incl0 - cnt[0], nat1 = tot0 + incl1 - cnt[1];   // offsets without padding
-            // ... with every layer's start moved up (by at most 3 far-away entries) so that it differs mod 16
-            // from the three layer starts before it.  A lane's scan reads entry (its window's end - nsteps + j)
-            // at step j, the window ends are layer starts, a ds_read_b128 serves 16 lanes (targets of ~4
-            // consecutive cells) per LDS cycle, and entries that are equal mod 16 share their four banks:
-            // with the natural layer size (~72 = 8 mod 16) every second layer collides (measured: 55 % of
-            // the LDS cycles were bank-conflict cycles).
-            int start = 0, shift0 = 0, shift1 = 0, r1 = -1, r2 = -1, r3 = -1, nat_prev = 0;
-            const int layer0 = lane / 9, layer1 = (lane + 64) / 9;
-            for (int Ly = 0; Ly <= nlayers; ++Ly) {
-                const int q = 9 * Ly;
-                const int nat = Ly == nlayers ? nat_total
-                                              : (q < kWave ? __builtin_amdgcn_readlane(nat0, q) : __builtin_amdgcn_readlane(nat1, q - kWave));
-                start += nat - nat_prev;
-                nat_prev = nat;
-                if (Ly > 0 && Ly < nlayers) {
-                    for (int bump = 0; bump < 3 && ((start & 15) == r1 || (start & 15) == r2 || (start & 15) == r3); ++bump) {
-                        if (lane == 0 && start < kLaneTileCap) tile[start] = far_entry;
-                        ++start;
-                    }
-                }
-                r3 = r2;
-                r2 = r1;
-                r1 = start & 15;
-                if (lane == 0) s_layer[Ly] = start;
-                if (Ly == layer0) shift0 = start - nat;
-                if (Ly == layer1) shift1 = start - nat;
-            }
-            total = start;
-            off[0] = nat0 + shift0;
-            off[1] = nat1 + shift1;
+            nat_total = tot0 + __builtin_amdgcn_readlane(incl1, kWave - 1);
+            nat[0] = incl0 - cnt[0];
+            nat[1] = tot0 + incl1 - cnt[1];
         }
 #ifdef MM_LANE_STAMPS
-        asm volatile("" ::"v"(off[0]), "v"(off[1]));
+        asm volatile("" ::"v"(nat[0]), "v"(nat[1]));
 #endif
         MM_STAMP(1);   // cell extents arrived, offsets computed
-        if (total > kLaneTileCap) {
+        if (nat_total > kLaneTileCap) {
             // too full for the tile (a locally much denser region): the item's targets go to the next density
             // level when there is one (a grid with smaller cells there), else to the generic kernel
             int base = 0;
@@ -1996,53 +1975,77 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 for (int q = lane; q < tn; q += kWave)
                     fb_list[base + q] = sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
             }
-            continue;
+            return;
         }
-        // ---- stage, step 1: every entry's position in the sorted array (the cells' owners know them) ...
+        // ---- stage, step 1: every entry's position in the sorted array, in cell order (the cells' owners know them) ...
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            for (int q = 0; q < cnt[b]; ++q) reinterpret_cast<int *>(tile + off[b] + q)[3] = s0[b] + q;
-        if (lane < kLanePad) tile[total + lane] = far_entry;   // a window read may run past the tile's end
+            for (int q = 0; q < cnt[b]; ++q) reinterpret_cast<int *>(tile + nat[b] + q)[3] = s0[b] + q;
+        s_hist[lane] = 0;
         wave_sync();
         MM_STAMP(2);   // positions written
-        // ... step 2: entry 64 t + lane is fetched by lane `lane` -- every lane busy, six records in flight per
-        // lane (copying cell by cell was a chain of round trips)
-        constexpr int kTrips = 11;  // ~10 trips per tile: all of them in flight at once, ONE global round trip
-        for (int e0 = 0; e0 < total; e0 += kTrips * kWave) {
-            int pos[kTrips];
-            double2 xy[kTrips];
-            double zc[kTrips];
+        // ... step 2: entry 64 u + lane is fetched by lane `lane` -- the WHOLE tile sits in registers at once
+        // (kLaneTrips records per lane, all in flight together: one global round trip), is converted to fp32
+        // relative to the strip corner and BINNED BY THIN LAYER: a cell layer is cut into T slices along z, the
+        // tile is kept in (thin layer, arrival) order, and a target's window is the 2 W + 1 thin layers around
+        // its own instead of three whole cell layers (7 / 4 of a cell edge instead of 3: 40 % fewer candidates,
+        // and candidates are what the scan's vector instructions are spent on).  The rank inside the thin layer
+        // comes back from the LDS atomic that counts it.
+        const int NL = nlayers * T;                              // <= kLaneThinMax (the launcher checks)
+        const float zbase = (float)((double)(za - cz0) * g.hz);  // z of the tile's bottom, relative to the strip corner
+        const double th = g.hz / (double)T;                      // thickness of a thin layer
+        const float inv_t = (float)((double)T * g.ihz);
+        {
+            // (everything a lane holds of the tile stays in registers between the two LDS phases: the entries cannot be
+            // parked in their cell-order slots, which the final order overwrites)
+            int epos[kLaneTrips], ebin[kLaneTrips];   // ebin: thin layer | rank inside it << 8
+            float ex[kLaneTrips], ey[kLaneTrips], ez[kLaneTrips];
+            {
+                double2 xy[kLaneTrips];
+                double zc[kLaneTrips];
 #pragma unroll
-            for (int u = 0; u < kTrips; ++u) {
-                const int e = e0 + u * kWave + lane;
-                pos[u] = e < total ? reinterpret_cast<const int *>(tile + e)[3] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < kTrips; ++u) {
-                const double *rec = sorted_xyz + (i64)max(pos[u], 0) * kRec;
-                xy[u] = *reinterpret_cast<const double2 *>(rec);
-                zc[u] = rec[2];
-            }
-#pragma unroll
-            for (int u = 0; u < kTrips; ++u)
-                if (pos[u] >= 0) {
-                    // non-finite or absurdly far sources become far-away entries (never NaN in a key)
-                    const float fx = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
-                    const float fy = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
-                    const float fz = fminf(fmaxf((float)(zc[u] - oz), -kLaneFar), kLaneFar);
-                    float *dst = reinterpret_cast<float *>(tile + e0 + u * kWave + lane);
-                    *reinterpret_cast<float2 *>(dst) = make_float2(fx, fy);
-                    dst[2] = fz;
+                for (int u = 0; u < kLaneTrips; ++u) {
+                    const int e = u * kWave + lane;
+                    epos[u] = e < nat_total ? reinterpret_cast<const int *>(tile + e)[3] : -1;
                 }
+#pragma unroll
+                for (int u = 0; u < kLaneTrips; ++u) {
+                    const double *rec = sorted_xyz + (i64)max(epos[u], 0) * kRec;
+                    xy[u] = *reinterpret_cast<const double2 *>(rec);
+                    zc[u] = rec[2];
+                }
+#pragma unroll
+                for (int u = 0; u < kLaneTrips; ++u) {
+                    // non-finite or absurdly far sources become far-away entries (never NaN in a key)
+                    ex[u] = fminf(fmaxf((float)(xy[u].x - ox), -kLaneFar), kLaneFar);
+                    ey[u] = fminf(fmaxf((float)(xy[u].y - oy), -kLaneFar), kLaneFar);
+                    ez[u] = fminf(fmaxf((float)(zc[u] - oz), -kLaneFar), kLaneFar);
+                    const int tl = min(max((int)((ez[u] - zbase) * inv_t), 0), NL - 1);
+                    ebin[u] = tl;
+                    if (epos[u] >= 0) ebin[u] = tl | (atomicAdd(&s_hist[tl], 1) << 8);
+                }
+            }
+            wave_sync();   // every entry binned; every position read
+            // thin-layer starts: exclusive prefix over the bins, lane = thin layer (bins past NL are empty)
+            {
+                const int c = s_hist[lane];
+                int incl = c;
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const int a = __shfl_up(incl, d);
+                    if (lane >= d) incl += a;
+                }
+                s_thin[lane] = incl - c;
+                if (lane == kWave - 1) s_thin[kWave] = incl;
+            }
+            if (lane < kLanePad) tile[nat_total + lane] = far_entry;   // a window read may run past the tile's end
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < kLaneTrips; ++u)
+                if (epos[u] >= 0)
+                    tile[s_thin[ebin[u] & 255] + (ebin[u] >> 8)] = make_float4(ex[u], ey[u], ez[u], __int_as_float(epos[u]));
         }
-        wave_sync();   // tile and layer table staged
+        wave_sync();   // tile and thin-layer table staged
         MM_STAMP(3);   // records gathered, converted, in LDS
-
-        // widest window of the strip's cells: the trip count of every lane's scan
-        int maxwin = 0;
-        for (int cz = cz0; cz < cz1; ++cz)
-            maxwin = max(maxwin, s_layer[min(cz + 1, zb) - za + 1] - s_layer[max(cz - 1, za) - za]);
-        const int nsteps = (maxwin + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll;   // < 1024: the payload's 10 bits
 
         for (int r0 = 0; r0 < tn; r0 += kWave) {
             const bool valid = r0 + lane < tn;
@@ -2059,12 +2062,30 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 npw = zw.y;
             }
             const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
-            const int czl = min(max(cell_coord(pz, g.loz, g.ihz, g.nz), cz0), cz1 - 1);
-            const int we = s_layer[min(czl + 1, zb) - za + 1];
-            // every lane reads nsteps entries ending at its window's end (or starting at the tile's start)
-            const int wbase = max(we - nsteps, 0);
             const float tx = finite ? (float)(px - ox) : 0.f, ty = finite ? (float)(py - oy) : 0.f,
                         tz = finite ? (float)(pz - oz) : 0.f;
+            // the target's thin layer, by the arithmetic that binned the sources
+            const int tlz = min(max((int)((tz - zbase) * inv_t), 0), NL - 1);
+            double ed[NE];
+            int ei[NE];
+            int rank[NE];
+            bool hand_over;
+            // First with the narrow window (W thin layers either way); when any target of the round cannot be
+            // certified in it -- its k-th neighbour is farther than the window's faces, or the window holds too few
+            // sources: sparser places than the grid was laid out for -- the round is done again with a full cell
+            // layer either way, the guarantee of a 3x3x3 block.
+            for (int Wc = kRetry ? W : T;;) {
+            const int lo = max(tlz - Wc, 0), hi = min(tlz + Wc, NL - 1);
+            const int we = s_thin[hi + 1];
+            int nsteps;
+            {
+                // the longest window of the round: the trip count of every lane's scan (< 1024: the payload's 10 bits)
+                int wl = valid ? we - s_thin[lo] : 0;
+                for (int off = 32; off > 0; off >>= 1) wl = max(wl, __shfl_xor(wl, off));
+                nsteps = max((__builtin_amdgcn_readfirstlane(wl) + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll, kLaneUnroll);
+            }
+            // every lane reads nsteps entries ending at its window's end (or starting at the tile's start)
+            const int wbase = max(we - nsteps, 0);
             float d[L];
 #pragma unroll
             for (int s = 0; s < L; ++s) d[s] = 3.0e38f;
@@ -2110,8 +2131,6 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 #endif
             MM_STAMP(4);   // scan
             // ---- exact fp64 distance (reference arithmetic) and source id of the K + 1 best keys
-            double ed[NE];
-            int ei[NE];
             {
                 int pos[NE];
 #pragma unroll
@@ -2136,8 +2155,35 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             asm volatile("" ::"v"(ed[0]), "v"(ed[NE - 1]));
 #endif
             MM_STAMP(5);   // exact distances here
+            double kth = INFINITY;
+            if (!kRowsInLds) {
+                // Short rows: the candidates come in KEY order, which is the exact order except where two exact
+                // distances lie within the keys' resolution (2^-13 relative: a few per cent of the targets have one
+                // such pair among their nine).  Adjacent swaps on (d2, id) until every lane's list is in order --
+                // usually one pass -- instead of counting 72 ranks and selecting every output slot out of nine.
+                for (;;) {
+                    bool inorder = true;
+#pragma unroll
+                    for (int e = 0; e + 1 < NE; ++e) inorder = inorder && !before(ed[e + 1], ei[e + 1], ed[e], ei[e]);
+                    if (!__any(valid && !inorder)) break;
+#pragma unroll
+                    for (int e = 0; e + 1 < NE; ++e) {
+                        const bool sw = before(ed[e + 1], ei[e + 1], ed[e], ei[e]);
+                        const double da = ed[e], db = ed[e + 1];
+                        const int ia = ei[e], ib = ei[e + 1];
+                        ed[e] = sw ? db : da;
+                        ed[e + 1] = sw ? da : db;
+                        ei[e] = sw ? ib : ia;
+                        ei[e + 1] = sw ? ia : ib;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    rank[e] = e;
+                    if (e == kout - 1) kth = ed[e];
+                }
+            } else {
             // rank by exact d2; bit-equal distances (rare) redo the ranks lexicographically by (d2, id)
-            int rank[NE];
             unsigned seen = 0u;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
@@ -2160,29 +2206,42 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 }
             }
             // the exact k-th distance
-            double kth = INFINITY;
 #pragma unroll
             for (int e = 0; e < NE; ++e)
                 if (rank[e] == kout - 1) kth = ed[e];
-            bool hand_over = !finite || !(kth < INFINITY);
+            }
+            hand_over = !finite || !(kth < INFINITY);
             {
                 // every source outside the list lies at an exact distance >= lb (header comment)
+                const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
+                                             (double)(Z + 1) * g.hz);
                 const float B = d[L - 1];
                 if (B < kLaneFarKey) {
-                    const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
-                                                 (double)(Z + 1) * g.hz);
-                    const double lb = (sqrt((double)B) * (1.0 - 0x1p-12) - E) * (1.0 - 4.0 * kU);
+                    // (v_sqrt_f32 is within 1 ulp: 2^-21 more off the factor covers it)
+                    const double lb = ((double)__builtin_amdgcn_sqrtf(B) * (1.0 - 0x1p-12 - 0x1p-21) - E) * (1.0 - 4.0 * kU);
                     if (!(lb > 0.0 && kth < lb * lb * (1.0 - 0x1p-40))) hand_over = true;
                 }
-                // could a nearer source sit outside the target's 3x3x3 block?
-                const bool all_x = (cx - 1 <= 0) && (cx + 1 >= g.nx - 1);
-                const bool all_y = (cy - 1 <= 0) && (cy + 1 >= g.ny - 1);
-                const bool all_z = (czl - 1 <= 0) && (czl + 1 >= g.nz - 1);
-                if (!(all_x && all_y && all_z)) {
-                    const double bound = block_bound(g, px, py, pz, cx, cy, czl, 1);
-                    if (!(bound > 0.0 && kth < bound * bound)) hand_over = true;
-                }
+                // could a nearer source sit outside what was scanned?  Beyond the x / y faces of the 3 x 3 columns
+                // (as block_bound: faces that still have cells behind them) ...
+                double bound = INFINITY;
+                const double slack_x = 1e-9 * g.hx, slack_y = 1e-9 * g.hy;
+                if (cx - 1 > 0) bound = fmin(bound, (px - (g.lox + (double)(cx - 1) * g.hx)) - slack_x);
+                if (cx + 1 < g.nx - 1) bound = fmin(bound, ((g.lox + (double)(cx + 2) * g.hx) - px) - slack_x);
+                if (cy - 1 > 0) bound = fmin(bound, (py - (g.loy + (double)(cy - 1) * g.hy)) - slack_y);
+                if (cy + 1 < g.ny - 1) bound = fmin(bound, ((g.loy + (double)(cy + 2) * g.hy) - py) - slack_y);
+                // ... or in a thin layer below / above the window.  The planes between thin layers are taken in the
+                // tile's fp32 frame, where the sources were binned: a source outside the window has an fp32 z beyond
+                // the plane (the bin arithmetic is off by < 1e-5 of a thin layer), its coordinate and the target's
+                // are within E of the exact ones.  A clipped window ends at the tile's own face, which has sources
+                // behind it unless it is the grid's.
+                const double zs = E + 1e-4 * th;
+                if (lo > 0 || za > 0) bound = fmin(bound, ((double)tz - ((double)zbase + (double)lo * th)) - zs);
+                if (hi < NL - 1 || zb < g.nz - 1) bound = fmin(bound, (((double)zbase + (double)(hi + 1) * th) - (double)tz) - zs);
+                if (bound < INFINITY && !(bound > 0.0 && kth < bound * bound)) hand_over = true;
             }
+            if (!kRetry || Wc >= T || !__any(valid && hand_over)) break;
+            Wc = T;
+            }   // (attempts)
             if (dist_out && valid && !hand_over) {
 #pragma unroll
                 for (int e = 0; e < NE; ++e)
@@ -2208,15 +2267,10 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                     }
                 }
             } else {
-                // short rows: the id of rank r is picked out of the K + 1 entries in registers
+                // short rows: entry r IS rank r (put in order above)
                 int out[K];
 #pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    int v = 0;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) v = rank[e] == r ? ei[e] : v;
-                    out[r] = v;
-                }
+                for (int r = 0; r < K; ++r) out[r] = ei[r];
                 if (valid && !hand_over) {
                     IDX *row = idx_out + i * kout;
                     if (sizeof(IDX) == 4 && K % 4 == 0 && kout == K) {
@@ -2277,6 +2331,7 @@ __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__re
 constexpr int kLaneMaxK = 20;
 struct LaneWork {
     int Z;
+    int T, W;            // thin layers per cell layer, half-width of a target's window in thin layers
     int sorted_rows;     // rows and hand-overs by position in the cell-sorted order
     i64 nstrips_total;   // columns x strips per column
     i64 max_items;       // upper bound on the work items: strips + targets / (64 * kLaneRounds)
@@ -2401,14 +2456,12 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         (void)hipMemsetAsync(lane->items, 0xff, (size_t)lane->max_items * sizeof(int2), ctx->stream);   // -1: no item
         hipLaunchKernelGGL(lane_items_fill_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, lane->item_start,
                            lane->nstrips_total, lane->items);
-        static const i64 force_grid = getenv("MM_KNN_LANE_GRID") ? atoll(getenv("MM_KNN_LANE_GRID")) : 0;
-        i64 wgs = force_grid > 0 ? force_grid : lane->max_items;
-        wgs = (wgs + 7) / 8 * 8;
-        if (wgs > ((i64)1 << 22)) wgs = (i64)1 << 22;
+        const i64 wgs = lane->max_items;   // one workgroup per slot (a multiple of 8; < 2^31: npts and the strip count are)
         if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
         hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
                            ix->cell_start, ix->sorted_xyz, ix->ndim, kout, tstart, tsorted, idx, dist, fb_list, fb_count,
-                           lane->items, (int)lane->max_items, lane->Z, per_item, lane->sorted_rows, down_list, down_count);
+                           lane->items, (int)lane->max_items, lane->Z, per_item, lane->sorted_rows, down_list, down_count,
+                           lane->T, K <= 8 ? lane->W : lane->T);   // (long lists reach farther: a full cell layer either way)
         if (record_stage) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
         return;
     }
@@ -2792,6 +2845,14 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
         lane_work.Z = force_z >= 1 && force_z <= kLaneZMax ? force_z : kLaneZ;
         if (lane_work.Z > ix->dims[2]) lane_work.Z = ix->dims[2];
+        // thin layers: (Z + 2) T of them must fit the 64 lanes of the prefix sum; the window never reaches past one
+        // cell layer (W <= T).  MM_KNN_LANE_T / MM_KNN_LANE_W: tuning experiments only.
+        static const int force_t = getenv("MM_KNN_LANE_T") ? atoi(getenv("MM_KNN_LANE_T")) : 0;
+        static const int force_w = getenv("MM_KNN_LANE_W") ? atoi(getenv("MM_KNN_LANE_W")) : 0;
+        lane_work.T = force_t >= 1 ? force_t : kLaneThin;
+        while (lane_work.T > 1 && (lane_work.Z + 2) * lane_work.T > kLaneThinMax) --lane_work.T;
+        lane_work.W = force_w >= 1 ? force_w : (lane_work.T == kLaneThin ? kLaneWin : lane_work.T);
+        if (lane_work.W > lane_work.T) lane_work.W = lane_work.T;
         const i64 nstrips = (ix->dims[2] + lane_work.Z - 1) / lane_work.Z;
         lane_work.nstrips_total = (i64)ix->dims[0] * ix->dims[1] * nstrips;
         // (slots: 8 per row of the permuted list, so up to 7 more than items; a multiple of 8 = the grid)

@@ -98,7 +98,7 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     // acceptance, and the operator rows are only materialised when the caller asks for them (both
     // pointers).  Many components: 8 gathers per component inside the register-heavy locate kernel
     // cost more than writing the rows and streaming them through the gather kernel.
-    const int64_t fuse_max = getenv("MM_FUSE_GATHER_MAXC") ? atoll(getenv("MM_FUSE_GATHER_MAXC")) : kFuseGatherMaxComp;
+    static const int64_t fuse_max = getenv("MM_FUSE_GATHER_MAXC") ? atoll(getenv("MM_FUSE_GATHER_MAXC")) : kFuseGatherMaxComp;
     const bool want_values = out_d && ncomp > 0;
     const bool fuse_gather = want_values && ncomp <= fuse_max;
     if (!(enc && w)) {
@@ -257,15 +257,6 @@ static mm_context *legacy_context()
 }
 
 namespace {
-struct DeviceBuf {
-    void *p = nullptr;
-    ~DeviceBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
-};
-
 template <typename T>
 i64 max_plus_one(const T *a, size_t n)
 {
@@ -300,23 +291,27 @@ extern "C" void centroid(long long ndim, long long nelem, long long nper, long l
     }
     const size_t nconn = (size_t)nelem * (size_t)nper;
     const i64 npoints = max_plus_one(connectivity, nconn);
-    DeviceBuf d_conn, d_pts, d_out;
-    hipError_t e = d_conn.alloc(nconn * sizeof(i64));
-    if (e == hipSuccess) e = d_pts.alloc((size_t)npoints * ndim * sizeof(double));
-    if (e == hipSuccess) e = d_out.alloc((size_t)nelem * ndim * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_conn.p, connectivity, nconn * sizeof(i64), hipMemcpyHostToDevice, ctx->stream);
+    // device copies from the context's grow-only cache (no hipMalloc / hipFree per call)
+    void *d_conn = nullptr, *d_pts = nullptr, *d_out = nullptr;
+    if (mm_buffer_get(ctx, MM_BUF_L_CONN, nconn * sizeof(i64), &d_conn) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)npoints * ndim * sizeof(double), &d_pts) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_W, (size_t)nelem * ndim * sizeof(double), &d_out) != MM_OK) {
+        (void)legacy_fail("centroid");
+        return;
+    }
+    hipError_t e = hipMemcpyAsync(d_conn, connectivity, nconn * sizeof(i64), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(d_pts.p, points, (size_t)npoints * ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(d_pts, points, (size_t)npoints * ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "centroid: %s", hipGetErrorString(e));
         (void)legacy_fail("centroid");
         return;
     }
-    if (mm_centroid(ctx, ndim, nelem, nper, (const int64_t *)d_conn.p, (const double *)d_pts.p, (double *)d_out.p) != MM_OK) {
+    if (mm_centroid(ctx, ndim, nelem, nper, (const int64_t *)d_conn, (const double *)d_pts, (double *)d_out) != MM_OK) {
         (void)legacy_fail("centroid");
         return;
     }
-    e = hipMemcpyAsync(centroid_out, d_out.p, (size_t)nelem * ndim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    e = hipMemcpyAsync(centroid_out, d_out, (size_t)nelem * ndim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "centroid: %s", hipGetErrorString(e));
@@ -345,31 +340,35 @@ extern "C" long long triLinearInterpolator(long long k, long long npoints, long 
         }
     const i64 nelem = max_plus_one(nn, nnn);
     const i64 nnodes = max_plus_one(connectivity, (size_t)nelem * 8);
-    DeviceBuf d_nn, d_conn, d_enc, d_nodes, d_w, d_pts;
-    hipError_t e = d_nn.alloc(nnn * sizeof(i64));
-    if (e == hipSuccess) e = d_conn.alloc((size_t)nelem * 8 * sizeof(i64));
-    if (e == hipSuccess) e = d_enc.alloc((size_t)npoints * 8 * sizeof(i64));
-    if (e == hipSuccess) e = d_nodes.alloc((size_t)nnodes * 3 * sizeof(double));
-    if (e == hipSuccess) e = d_w.alloc((size_t)npoints * 8 * sizeof(double));
-    if (e == hipSuccess) e = d_pts.alloc((size_t)npoints * 3 * sizeof(double));
+    // device copies from the context's grow-only cache: the reference's exodus_2_gll flow calls this symbol once per
+    // GLL point of the element (scripts/cli.py:183-195: 125 calls on the same mesh), and six hipMalloc / hipFree pairs
+    // of mesh-sized buffers per call cost more than the kernels
+    void *d_nn = nullptr, *d_conn = nullptr, *d_enc = nullptr, *d_nodes = nullptr, *d_w = nullptr, *d_pts = nullptr;
+    if (mm_buffer_get(ctx, MM_BUF_L_NN, nnn * sizeof(i64), &d_nn) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_CONN, (size_t)nelem * 8 * sizeof(i64), &d_conn) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_ENC, (size_t)npoints * 8 * sizeof(i64), &d_enc) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)nnodes * 3 * sizeof(double), &d_nodes) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_W, (size_t)npoints * 8 * sizeof(double), &d_w) != MM_OK ||
+        mm_buffer_get(ctx, MM_BUF_L_PTS, (size_t)npoints * 3 * sizeof(double), &d_pts) != MM_OK)
+        return legacy_fail("triLinearInterpolator");
     hipStream_t s = ctx->stream;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nn.p, nn, nnn * sizeof(i64), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_conn.p, connectivity, (size_t)nelem * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nodes.p, nodes, (size_t)nnodes * 3 * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    hipError_t e = hipMemcpyAsync(d_nn, nn, nnn * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conn, connectivity, (size_t)nelem * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, nodes, (size_t)nnodes * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice, s);
     // in-place contract: rows of failed points keep the caller's contents
-    if (e == hipSuccess) e = hipMemcpyAsync(d_enc.p, enc, (size_t)npoints * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_w.p, weights, (size_t)npoints * 8 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_enc, enc, (size_t)npoints * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, weights, (size_t)npoints * 8 * sizeof(double), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "triLinearInterpolator: %s", hipGetErrorString(e));
         return legacy_fail("triLinearInterpolator");
     }
-    const int64_t nfailed = mm_locate_hex8(ctx, k, npoints, (const int64_t *)d_nn.p, (const int64_t *)d_conn.p, nelem, 0,
-                                           (int64_t *)d_enc.p, (const double *)d_nodes.p, (double *)d_w.p,
-                                           (const double *)d_pts.p);
+    const int64_t nfailed = mm_locate_hex8(ctx, k, npoints, (const int64_t *)d_nn, (const int64_t *)d_conn, nelem, 0,
+                                           (int64_t *)d_enc, (const double *)d_nodes, (double *)d_w,
+                                           (const double *)d_pts);
     if (nfailed < 0) return legacy_fail("triLinearInterpolator");
-    e = hipMemcpyAsync(enc, d_enc.p, (size_t)npoints * 8 * sizeof(i64), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w.p, (size_t)npoints * 8 * sizeof(double), hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(enc, d_enc, (size_t)npoints * 8 * sizeof(i64), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w, (size_t)npoints * 8 * sizeof(double), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "triLinearInterpolator: %s", hipGetErrorString(e));
