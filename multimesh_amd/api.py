@@ -266,35 +266,98 @@ def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to
     return (out, nfailed) if return_nfailed else out
 
 
-def assess_layers(layer_ids, layers):
-    """The list form of the reference's ``utils._assess_layers`` (utils.py:382-408): ``layers`` = "all" or a
-    list of layer numbers that must lie within the mesh's own; returned in descending order for "all", as the
-    reference sorts them.  The Earth presets ("crust", "mantle", "core", "nocore": utils.py:413-440) need the
-    mesh's moho / fluid metadata and are not part of the hot path."""
+def assess_layers(layer_ids, layers, fluid=None, moho_idx=None):
+    """The reference's ``utils._assess_layers`` (utils.py:382-440) on arrays: ``layer_ids`` = the mesh's
+    ``layer`` elemental field; ``layers`` = "all", a list of layer numbers (which must lie within the mesh's
+    own), one layer number, or an Earth preset.  The mesh's layers are sorted in DESCENDING order, "outwards from
+    the core" reversed, as the reference sorts them (:396); with ``o_core_idx`` = the place in that order of the
+    layer of the first fluid element (:426-429):
+
+        "crust"  -> layers[:moho_idx]            "mantle" -> layers[moho_idx:o_core_idx]
+        "core"   -> layers[o_core_idx:]          "nocore" -> layers[:o_core_idx]
+
+    ``fluid``: the mesh's ``fluid`` elemental field (needed by "mantle", "core", "nocore"); ``moho_idx``: the
+    mesh's global string of that name (``mesh.global_strings["moho_idx"]``, needed by "crust" and "mantle")."""
     mesh_layers = np.sort(np.unique(np.asarray(layer_ids)))[::-1].astype(int)
-    if isinstance(layers, str):
-        if layers != "all":
-            raise ValueError("layers must be 'all' or a list of layer numbers (the Earth presets need mesh metadata)")
+    if isinstance(layers, (list, tuple, np.ndarray)):
+        layers = [int(x) for x in np.atleast_1d(layers)]
+        if max(layers) > mesh_layers.max() or min(layers) < mesh_layers.min():
+            raise ValueError("Requested layers not in mesh")
+        return layers
+    if isinstance(layers, (int, np.integer)):
+        if int(layers) not in mesh_layers:
+            raise ValueError("Requested layer not in mesh")
+        return [int(layers)]
+    available_layers = ["all", "crust", "mantle", "core", "nocore"]
+    if not isinstance(layers, str):
+        raise ValueError(f"Input for layers needs to be a list of one of: {available_layers}")
+    if layers == "all":
         return [int(x) for x in mesh_layers]
-    layers = [int(x) for x in np.atleast_1d(layers)]
-    if max(layers) > mesh_layers.max() or min(layers) < mesh_layers.min():
-        raise ValueError("Requested layers not in mesh")
-    return layers
+    if layers not in available_layers:
+        raise ValueError(f"Only allowed string layer inputs are: {available_layers}")
+    if layers in ("crust", "mantle"):
+        if moho_idx is None:
+            raise ValueError(f'layers="{layers}" needs the mesh\'s moho_idx (global string of the Salvus mesh)')
+        moho_idx = int(moho_idx)
+    if layers == "crust":
+        return [int(x) for x in mesh_layers[:moho_idx]]
+    if fluid is None:
+        raise ValueError(f'layers="{layers}" needs the mesh\'s `fluid` elemental field')
+    fluid_elements = np.where(np.asarray(fluid) == 1)[0]
+    if len(fluid_elements) == 0:
+        raise ValueError(f'layers="{layers}": the mesh has no fluid element (no outer core)')
+    o_core_layer = np.asarray(layer_ids)[fluid_elements[0]]
+    o_core_idx = int(np.where(mesh_layers == int(o_core_layer))[0][0])
+    if layers == "mantle":
+        picked = mesh_layers[moho_idx:o_core_idx]
+    elif layers == "core":
+        picked = mesh_layers[o_core_idx:]
+    else:   # "nocore"
+        picked = mesh_layers[:o_core_idx]
+    return [int(x) for x in picked]
+
+
+def _h5py_or_none():
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        return None
 
 
 def load_stored_layer_operator(stored_array):
-    """``interp_info`` of the layered drivers (reference interpolator.py:1035-1044: ``coeffs/<layer>`` and
-    ``elements/<layer>`` datasets of interp_info.h5); an ``.npz`` with the same keys since h5py is absent."""
-    path = os.path.join(stored_array, "interp_info.npz") if stored_array else None
-    if not path or not os.path.exists(path):
+    """``interp_info`` of the layered drivers: ``coeffs/<layer>`` and ``elements/<layer>`` datasets of
+    ``interp_info.h5`` (reference interpolator.py:1035-1044) when h5py is importable -- a cache the reference wrote
+    is read as it stands --, else (or when only that file exists) the same keys in ``interp_info.npz``."""
+    if not stored_array:
         return None
-    with np.load(path) as f:
-        return ({k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("elements/")},
-                {k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("coeffs/")})
+    h5, npz = os.path.join(stored_array, "interp_info.h5"), os.path.join(stored_array, "interp_info.npz")
+    h5py = _h5py_or_none()
+    if h5py is not None and os.path.exists(h5):
+        with h5py.File(h5, "r") as f:
+            return ({k: f["elements"][k][:] for k in f["elements"].keys()},
+                    {k: f["coeffs"][k][:] for k in f["coeffs"].keys()})
+    if os.path.exists(npz):
+        with np.load(npz) as f:
+            return ({k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("elements/")},
+                    {k.split("/", 1)[1]: f[k] for k in f.files if k.startswith("coeffs/")})
+    if os.path.exists(h5):
+        raise ImportError(f"{h5} exists but h5py is not importable here: cannot read the stored operator")
+    return None
 
 
 def save_stored_layer_operator(stored_array, elements, coeffs):
+    """Writes ``interp_info.h5`` in the reference's layout (interpolator.py:1061-1066) when h5py is importable,
+    ``interp_info.npz`` with the same keys otherwise."""
     os.makedirs(stored_array, exist_ok=True)
+    h5py = _h5py_or_none()
+    if h5py is not None:
+        with h5py.File(os.path.join(stored_array, "interp_info.h5"), "w") as f:
+            for k in coeffs.keys():
+                f.create_dataset(f"coeffs/{k}", data=coeffs[k])
+            for k in elements.keys():
+                f.create_dataset(f"elements/{k}", data=elements[k])
+        return
     arrays = {f"elements/{k}": v for k, v in elements.items()}
     arrays.update({f"coeffs/{k}": v for k, v in coeffs.items()})
     np.savez(os.path.join(stored_array, "interp_info.npz"), **arrays)
@@ -302,7 +365,7 @@ def save_stored_layer_operator(stored_array, elements, coeffs):
 
 def interpolate_gll_to_gll_layered(mesh_a: GllMesh, layer_a, target_gll_points, layer_b, params_to_interp,
                                    layers="all", nelem_to_search=30, tolerance=1.05, stored_array=None,
-                                   existing=None, context=None):
+                                   existing=None, context=None, fluid_a=None, moho_idx=None, acceptance="tolerance"):
     """The array core of ``gll_2_gll_layered_multi_two`` (reference interpolator.py:980-1082): for every
     layer, the unique element-nodal points of the TARGET elements of that layer are located among the
     SOURCE elements of the same layer only (a tree over just their centroids, :1053), with
@@ -313,7 +376,17 @@ def interpolate_gll_to_gll_layered(mesh_a: GllMesh, layer_a, target_gll_points, 
     sub-meshes -> ``mm_scatter_elements``.  ``stored_array``: the per-layer operator is kept as
     ``interp_info.npz`` (``coeffs/<layer>``, ``elements/<layer>``) and re-applied when it exists.
     Returns f64[C, E_t, P_t]; rows of target elements outside ``layers`` keep ``existing`` (zeros when not
-    given), like the fields of the reference's ``new_mesh``."""
+    given), like the fields of the reference's ``new_mesh``.
+
+    ``layers`` may be an Earth preset ("crust", "mantle", "core", "nocore"): resolved on the SOURCE mesh as the
+    reference does (``create_layer_mask(mesh=original_mesh, ...)``, :1019), from ``fluid_a`` (its ``fluid``
+    elemental field) and ``moho_idx`` (its global string) -- see :func:`assess_layers`.
+    ``acceptance="bbox"``: the acceptance loop of the two older drivers (``gll_2_gll_layered`` :288-439 and
+    ``gll_2_gll_layered_multi`` :442-618, through ``fill_value_array`` / ``_check_if_inside_element`` with
+    ``ignore_hard_elements=True``: bounding-box pre-test, |xi| <= 1.04, nearest-centre fallback) instead of
+    ``get_element_weights(snap_to_nearest=True)``: ``mm_locate_gll_bbox`` + ``mm_gather_elem`` per layer."""
+    if acceptance not in ("tolerance", "bbox"):
+        raise ValueError("acceptance must be 'tolerance' or 'bbox'")
     ctx = context or default_context()
     tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
     layer_a, layer_b = np.asarray(layer_a), np.asarray(layer_b)
@@ -329,7 +402,7 @@ def interpolate_gll_to_gll_layered(mesh_a: GllMesh, layer_a, target_gll_points, 
     if stored is not None:
         print("No need for looping, we have the matrices")
     elements, coeffs = {}, {}
-    for layer in assess_layers(layer_a, layers):
+    for layer in assess_layers(layer_a, layers, fluid=fluid_a, moho_idx=moho_idx):
         key = str(layer)
         src_mask, tgt_mask = layer_a == layer, layer_b == layer
         if not tgt_mask.any():
@@ -342,6 +415,16 @@ def interpolate_gll_to_gll_layered(mesh_a: GllMesh, layer_a, target_gll_points, 
         if stored is not None:
             elements[key], coeffs[key] = stored[0][key], stored[1][key]
             vals = ctx.gather_elem(fields, elements[key], coeffs[key])
+        elif acceptance == "bbox":
+            print(f"Interpolating layer: {layer}")
+            # (the older drivers: a tree over the layer's element centroids, nelem_to_search candidates, the
+            # bounding-box loop; "hard" points -- final transform NaN -- keep the reference's constant xi)
+            tree = ctx.knn_build(np.ascontiguousarray(src.mean(axis=1)))
+            nn = tree.query(uniq, min(nelem_to_search, src.shape[0]))
+            el, co, _hard = ctx.locate_gll_bbox(mesh_a.shape_order, nn, src, uniq)
+            vals = ctx.gather_elem(fields, el, co)
+            if stored_array:
+                elements[key], coeffs[key] = el.numpy(), co.numpy()
         else:
             print("interpolating layer", layer, "...")
             if stored_array:
@@ -580,20 +663,63 @@ def gll_2_gll_layered_multi_two(from_gll, to_gll, layers, nelem_to_search=30, pa
     values = interpolate_gll_to_gll_layered(mesh_a, original_mesh.elemental_fields["layer"], new_mesh.points,
                                             new_mesh.elemental_fields["layer"], parameters, layers=layers,
                                             nelem_to_search=nelem_to_search, tolerance=tolerance,
-                                            stored_array=stored_array, existing=existing, context=context)
+                                            stored_array=stored_array, existing=existing, context=context,
+                                            **_layer_metadata(original_mesh))
     for i, param in enumerate(parameters):
         new_mesh.attach_field(name=param, data=values[i])
     _report(start)
 
 
-def _gll(name, row):
-    def f(*args, **kwargs):
-        raise NotImplementedError(f"{name}: {row}")
-    f.__name__ = name
-    return f
+def _layer_metadata(mesh):
+    """What the Earth presets of :func:`assess_layers` read off a Salvus mesh (reference utils.py:413-429)."""
+    moho = getattr(mesh, "global_strings", {}).get("moho_idx")
+    if isinstance(moho, bytes):
+        moho = moho.decode()
+    return {"fluid_a": mesh.elemental_fields.get("fluid"), "moho_idx": None if moho is None else int(moho)}
 
 
-gll_2_gll_layered = _gll("gll_2_gll_layered", "superseded in the reference by gll_2_gll_layered_multi_two, which is "
-                         "implemented here (same arguments); array core: interpolate_gll_to_gll_layered")
-gll_2_gll_layered_multi = _gll("gll_2_gll_layered_multi", "superseded in the reference by gll_2_gll_layered_multi_two, "
-                               "which is implemented here (same arguments); array core: interpolate_gll_to_gll_layered")
+def _gll_2_gll_layered_bbox(from_gll, to_gll, layers, nelem_to_search, parameters, stored_array, make_spherical,
+                            keep_existing, context):
+    from . import io as mio
+
+    if make_spherical:
+        raise NotImplementedError("map_to_sphere (reference interpolator.py:1085-1144) is Earth-specific "
+                                  "(out of scope, SURVEY.md §8)")
+    print("Initialization stage")
+    original_mesh = mio.SalvusMesh(from_gll, fast_mode=False)
+    new_mesh = mio.SalvusMesh(to_gll, fast_mode=False)
+    if isinstance(parameters, str) and parameters == "all":
+        parameters = list(original_mesh.element_nodal_fields.keys())
+    parameters = mio.pick_parameters(parameters)
+    mesh_a = GllMesh(original_mesh.points, original_mesh.shape_order,
+                     {p: original_mesh.element_nodal_fields[p] for p in parameters})
+    existing = np.stack([new_mesh.element_nodal_fields[p] for p in parameters]) if keep_existing else None
+    values = interpolate_gll_to_gll_layered(mesh_a, original_mesh.elemental_fields["layer"], new_mesh.points,
+                                            new_mesh.elemental_fields["layer"], parameters, layers=layers,
+                                            nelem_to_search=nelem_to_search, stored_array=stored_array,
+                                            existing=existing, context=context, acceptance="bbox",
+                                            **_layer_metadata(original_mesh))
+    for i, param in enumerate(parameters):
+        new_mesh.attach_field(name=param, data=values[i])
+
+
+def gll_2_gll_layered(from_gll, to_gll, layers, nelem_to_search=20, parameters="ISO", stored_array=None,
+                      make_spherical=False, context=None):
+    """Layer by layer with the bounding-box acceptance loop (reference api.py:158-211, interpolator.py:288-439);
+    elements of ``to_gll`` outside ``layers`` come out ZERO, as the reference's ``np.zeros_like`` fields do
+    (:421).  Superseded in the reference by :func:`gll_2_gll_layered_multi_two`."""
+    start = time.time()
+    _gll_2_gll_layered_bbox(from_gll, to_gll, layers, nelem_to_search, parameters, stored_array, make_spherical,
+                            keep_existing=False, context=context)
+    _report(start)
+
+
+def gll_2_gll_layered_multi(from_gll, to_gll, layers="nocore", nelem_to_search=20, parameters="all", threads=None,
+                            stored_array=None, make_spherical=False, context=None):
+    """The same per layer in parallel (reference api.py:214-274, interpolator.py:442-618: a process pool over
+    the layers -- here every layer is a device pass, ``threads`` is accepted and ignored); elements outside
+    ``layers`` keep the values ``to_gll`` holds (:606)."""
+    start = time.time()
+    _gll_2_gll_layered_bbox(from_gll, to_gll, layers, nelem_to_search, parameters, stored_array, make_spherical,
+                            keep_existing=True, context=context)
+    _report(start)

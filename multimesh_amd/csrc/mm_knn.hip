@@ -1795,6 +1795,10 @@ constexpr int kLanePad = 16;           // far-away entries behind the tile (a wi
 constexpr int kLaneZ = 7;              // cells per strip: ~57 targets per round of 64 lanes at 8 targets per cell
 constexpr int kLaneZMax = 12;
 constexpr int kLaneRounds = 4;         // rounds (of 64 targets) per work item
+// (the packed prefix sums of the cell counts give each half 16 bits: counts are clamped to kLaneTileCap + 1, the lower
+// word sums 64 of them, the upper one the rest of the (Z + 2) x 9 cells)
+static_assert(64 * (kLaneTileCap + 1) < 65536 && ((kLaneZMax + 2) * 9 - 64) * (kLaneTileCap + 1) < 65536,
+              "knn_lane_kernel: a packed prefix sum of cell counts could wrap");
 constexpr float kLaneFar = 1e18f;      // sentinel coordinate (squares to 1e36 < FLT_MAX: keys stay finite)
 constexpr float kLaneFarKey = 1e30f;   // keys at or above this are sentinels / absurdly far sources
 

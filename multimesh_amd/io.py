@@ -48,7 +48,10 @@ class _MemoryDataset:
     dtype = property(lambda self: self._a.dtype)
 
     def __getitem__(self, key):
-        return self._a[key] if key != () else self._a.copy()
+        # (an ndarray key -- a boolean mask, a fancy index -- must not be compared with the empty tuple)
+        if isinstance(key, tuple) and len(key) == 0:
+            return self._a.copy()
+        return self._a[key]
 
     def __setitem__(self, key, value):
         self._a[key] = value

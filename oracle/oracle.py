@@ -66,6 +66,8 @@ def lib():
         L.mmo_hex8_weights.argtypes = [_f64p, _f64p]
         L.mmo_gll_coefficients.restype = None
         L.mmo_gll_coefficients.argtypes = [C.c_int, C.c_int, _f64p, _f64p]
+        L.mmo_set_gll_strict.restype = None
+        L.mmo_set_gll_strict.argtypes = [C.c_int]
         L.mmo_gll_inverse_transform.restype = None
         L.mmo_gll_inverse_transform.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f64p]
         L.mmo_locate_gll.restype = C.c_int64
@@ -168,6 +170,12 @@ def gll_inverse_transform(order, pnt, ctrl):
     xi = np.zeros(pnt.shape[0])
     lib().mmo_gll_inverse_transform(order, pnt.shape[0], pnt, ctrl, xi)
     return xi
+
+
+def set_gll_strict(on: bool) -> None:
+    """Route the GLL inverse transform through the independent strict statement (plain sums, no fma, Gaussian
+    solve, 1e-13): used by the tests to BOUND the production arithmetic, never by a parity comparison."""
+    lib().mmo_set_gll_strict(1 if on else 0)
 
 
 def locate_gll(order, nn, gll_points, points, tolerance=1.05, snap_to_nearest=False):

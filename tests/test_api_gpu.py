@@ -52,8 +52,6 @@ def test_interpolate_to_points_and_operator_split():
     enc, w, nfailed = api.interpolate_operator(a, pts, nelem_to_search=25)
     assert nfailed == nf and np.array_equal(enc, enc_o) and np.array_equal(w, w_o)
     assert np.array_equal(api.apply_operator(a, enc, w, ["VSV", "RHO"]), truth)
-    with pytest.raises(NotImplementedError):
-        api.gll_2_gll_layered("a.h5", "b.h5", "all")                            # superseded drivers name their successor
     try:
         import h5py  # noqa: F401
     except ImportError:
@@ -337,6 +335,56 @@ def test_layered_gll_to_gll_equals_the_per_layer_loop(tmp_path):
 
 
 @pytest.mark.gpu
+def test_layer_presets_and_the_bounding_box_acceptance_of_the_older_drivers():
+    # a 5-layer "Earth" in z with a fluid layer: the presets are resolved on the SOURCE mesh (reference
+    # interpolator.py:1019) exactly as utils._assess_layers does (:413-436), and acceptance="bbox" is the loop of
+    # gll_2_gll_layered / gll_2_gll_layered_multi (fill_value_array -> _check_if_inside_element)
+    from multimesh_amd import api, synth
+
+    order = 2
+    src = synth.gll_mesh(11, order, seed=1)
+    tgt = synth.gll_mesh(9, order, seed=7)
+    layer_a = np.minimum((src.mean(axis=1)[:, 2] * 5).astype(int), 4) + 1        # layers 1..5, 5 = top
+    layer_b = np.minimum((tgt.mean(axis=1)[:, 2] * 5).astype(int), 4) + 1
+    fluid_a = (layer_a == 2).astype(float)                                       # the "outer core"
+    fields = np.stack([1.0 + synth.field_smooth(src.reshape(-1, 3)).reshape(src.shape[:2]) ** 2 + layer_a[:, None]])
+    mesh = api.GllMesh(src, order, {"VSV": fields[0]})
+    moho_idx = 1
+    # reference utils.py:396, 411-436 spelled out
+    mesh_layers = np.sort(np.unique(layer_a))[::-1].astype(int)
+    o_core = np.where(mesh_layers == layer_a[np.where(fluid_a == 1)[0][0]])[0][0]
+    presets = {"crust": mesh_layers[:moho_idx], "mantle": mesh_layers[moho_idx:o_core], "core": mesh_layers[o_core:],
+               "nocore": mesh_layers[:o_core], "all": mesh_layers}
+    for name, want_layers in presets.items():
+        assert api.assess_layers(layer_a, name, fluid=fluid_a, moho_idx=moho_idx) == [int(x) for x in want_layers]
+    existing = np.full((1,) + tgt.shape[:2], -3.0)
+    for name in ("nocore", "mantle"):
+        want, _ = _layered_oracle(src, layer_a, fields, tgt, layer_b, list(presets[name]), order, 30, 1.05)
+        got = api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV"], layers=name, fluid_a=fluid_a,
+                                                 moho_idx=moho_idx, existing=existing)
+        inside = np.isin(layer_b, presets[name])
+        assert np.array_equal(got[:, inside], want[:, inside]) and np.all(got[:, ~inside] == -3.0)
+    with pytest.raises(ValueError, match="moho_idx"):
+        api.assess_layers(layer_a, "crust", fluid=fluid_a)
+    with pytest.raises(ValueError, match="fluid"):
+        api.assess_layers(layer_a, "core")
+    # the older drivers' acceptance loop, per layer (reference interpolator.py:1516-1538)
+    store = None
+    got = api.interpolate_gll_to_gll_layered(mesh, layer_a, tgt, layer_b, ["VSV"], layers="nocore", fluid_a=fluid_a,
+                                             moho_idx=moho_idx, nelem_to_search=20, acceptance="bbox", stored_array=store)
+    want = np.zeros_like(got)
+    for layer in presets["nocore"]:
+        sm, tm = layer_a == layer, layer_b == layer
+        nodes = tgt[tm]
+        uniq, inv = np.unique(nodes.reshape(-1, 3), return_inverse=True, axis=0)
+        nn, _ = O.knn_ckdtree(src[sm].mean(axis=1), uniq, 20)
+        elem, co, _ = O.locate_gll_v1(order, nn, np.ascontiguousarray(src[sm]), uniq)
+        vals = O.gather_elem(np.ascontiguousarray(fields[:, sm]), elem, co)
+        want[:, tm] = vals[inv.reshape(-1)].reshape(nodes.shape[0], nodes.shape[1], -1).transpose(2, 0, 1)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
 def test_fluid_solid_fix_equals_the_reference_statements():
     from multimesh_amd import api
 
@@ -500,3 +548,20 @@ def test_query_model_and_layered_driver_on_model_files(tmp_path):
     assert np.array_equal(got, want.transpose(1, 0, 2))
     assert np.array_equal(got[layer_b == 0], before[layer_b == 0])        # other layers keep their values
     assert not np.array_equal(got[layer_b == 1], before[layer_b == 1])
+
+    # the two older drivers (reference api.py:158-274): bounding-box acceptance per layer; gll_2_gll_layered zeroes
+    # what it does not interpolate (interpolator.py:421), gll_2_gll_layered_multi keeps it (:606); a preset resolved
+    # from the source file's fluid flag ("nocore" = layers above the fluid one: here layer 1 above fluid layer 0)
+    fluid_a = 1.0 - layer_a
+    from_model = _gll_model(src, fields, ["VP", "VS"], fluid=fluid_a, layer=layer_a)
+    want_bbox = api.interpolate_gll_to_gll_layered(mesh_a, layer_a, tgt, layer_b, ["VP", "VS"], layers=[1], nelem_to_search=20,
+                                                   acceptance="bbox")
+    to_old = _gll_model(tgt, before, ["VP", "VS"], layer=layer_b)
+    api.gll_2_gll_layered(from_model, to_old, layers="nocore", parameters=["VP", "VS"])
+    assert np.array_equal(to_old["MODEL/data"][()], want_bbox.transpose(1, 0, 2))
+    assert not to_old["MODEL/data"][()][layer_b == 0].any()
+    to_multi = _gll_model(tgt, before, ["VP", "VS"], layer=layer_b)
+    api.gll_2_gll_layered_multi(from_model, to_multi, parameters=["VP", "VS"], threads=4)    # layers="nocore" by default
+    got_multi = to_multi["MODEL/data"][()]
+    assert np.array_equal(got_multi[layer_b == 1], want_bbox.transpose(1, 0, 2)[layer_b == 1])
+    assert np.array_equal(got_multi[layer_b == 0], before[layer_b == 0])

@@ -166,3 +166,36 @@ def test_bbox_variant_first_inside_box_wins_when_nothing_is_accepted():
     assert np.abs(xi).max() > 1.04                              # not acceptable in element e
     assert elem[0] == e and hard == 0
     assert np.array_equal(coeffs[0], O.gll_coefficients(1, np.array([0.645, -0.5])))
+
+
+def test_production_arithmetic_is_bounded_by_an_independent_strict_statement():
+    """ADVICE (round 2): the GLL Newton's stop test (1e-10) and its fused multiply-adds changed in the kernel and in
+    the oracle together, so kernel == oracle says nothing about the arithmetic itself.  The strict statement
+    (plain sums over the nodes, no fma, Gaussian solve with pivoting, 1e-13) is independent of both: on a
+    cfg5-shaped case (order-4 hexes, jittered, targets = GLL points of a finer mesh incl. points on element
+    faces) the accepted elements must be identical and xi / the coefficients must agree to 1e-9."""
+    from multimesh_amd import synth
+
+    for order, n_src, n_tgt in ((4, 7, 8), (2, 9, 11)):
+        src = synth.gll_mesh(n_src, order, seed=1)
+        tgt = np.unique(synth.gll_mesh(n_tgt, order, seed=7).reshape(-1, 3), axis=0)
+        rng = np.random.default_rng(order)
+        tgt = tgt[rng.choice(len(tgt), size=min(len(tgt), 6000), replace=False)]
+        nn, _ = O.knn_ckdtree(src.mean(axis=1), tgt, 20)
+        for snap in (False, True):
+            elem, co, miss = O.locate_gll(order, nn, src, tgt, 1.05, snap)
+            elem1, co1, hard1 = O.locate_gll_v1(order, nn, src, tgt)
+            O.set_gll_strict(True)
+            try:
+                elem_s, co_s, miss_s = O.locate_gll(order, nn, src, tgt, 1.05, snap)
+                elem1_s, co1_s, hard1_s = O.locate_gll_v1(order, nn, src, tgt)
+                # reference coordinates of the accepted element, both ways
+                found = elem >= 0
+                xi_s = np.array([O.gll_inverse_transform(order, tgt[i], src[elem[i]]) for i in np.nonzero(found)[0][:500]])
+            finally:
+                O.set_gll_strict(False)
+            xi_p = np.array([O.gll_inverse_transform(order, tgt[i], src[elem[i]]) for i in np.nonzero(found)[0][:500]])
+            assert miss == miss_s and np.array_equal(elem, elem_s)
+            assert hard1 == hard1_s and np.array_equal(elem1, elem1_s)
+            assert np.abs(xi_p - xi_s).max() <= 1e-9
+            assert np.abs(co - co_s).max() <= 1e-9 and np.abs(co1 - co1_s).max() <= 1e-9

@@ -98,3 +98,14 @@ def test_exodus_2d_quads(tmp_path):
     mio.write_exodus_classic(fn, xy, conn, {"T": xy[:, 0]})
     e = mio.Exodus(fn)
     assert e.ndim == 2 and e.nodes_per_element == 4 and np.array_equal(e.connectivity, conn) and np.array_equal(e.points, xy)
+
+
+def test_memory_dataset_takes_masks_and_fancy_indices_like_h5py():
+    from multimesh_amd import io as mio
+
+    h = mio.MemoryH5()
+    d = h.create_dataset("MODEL/data", data=np.arange(24.0).reshape(4, 3, 2))
+    mask = np.array([True, False, True, False])
+    assert np.array_equal(d[mask], np.arange(24.0).reshape(4, 3, 2)[mask])
+    assert np.array_equal(d[[0, 3]], np.arange(24.0).reshape(4, 3, 2)[[0, 3]])
+    assert np.array_equal(d[()], np.arange(24.0).reshape(4, 3, 2)) and d[()] is not d[()]
