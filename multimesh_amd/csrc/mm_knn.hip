@@ -1788,7 +1788,8 @@ __global__ __launch_bounds__(kWave, 4) void knn_strip_kernel(GridParams g, i64 n
 constexpr int kLaneTileCap = 768;      // sources per tile: (7 + 2) layers x 9 columns x ~8 = 648, + 4.7 sigma (Poisson)
 constexpr int kLaneTrips = kLaneTileCap / 64;   // staging trips: every lane holds its share of the WHOLE tile in registers
 constexpr int kLaneThin = 6;           // thin layers per cell layer (the tile is ordered by them, see the kernel's header)
-constexpr int kLaneWin = 5;            // half-width of a target's window in thin layers (first attempt; retried with kLaneThin): 5/6 of a cell edge
+constexpr int kLaneWin = 5;            // half-width of a target's window in thin layers, first attempt (5/6 of a cell edge: W = 4 is 4 % faster on
+                                       // mesh nodes, whose 8 nearest centroids are their own elements', and 25 % slower on random clouds); widened to kLaneThin on demand
 constexpr int kLaneThinMax = 64;       // thin layers per tile: one lane each in the prefix sum
 constexpr int kLaneUnroll = 8;
 constexpr int kLanePad = 16;           // far-away entries behind the tile (a window read may run past it by < 12 entries)
@@ -1820,6 +1821,39 @@ __device__ unsigned long long g_lane_stamps[kStampSlots * 8];   // per workgroup
 #else
 #define MM_STAMP(n) do { } while (0)
 #endif
+// Wave-wide inclusive prefix sum / maximum with DPP moves (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then the
+// row broadcasts 15 and 31): six VALU instructions with a few cycles of latency each, where __shfl_up is a
+// ds_bpermute through the LDS crossbar (~100 cycles each, six of them dependent).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from(int v, int fill)
+{
+    // lanes without a source lane (shifted in from outside the row / rows not in ROW_MASK) read `fill`
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += dpp_from<0x111, 0xF>(v, 0);   // row_shr:1
+    v += dpp_from<0x112, 0xF>(v, 0);   // row_shr:2
+    v += dpp_from<0x114, 0xF>(v, 0);   // row_shr:4
+    v += dpp_from<0x118, 0xF>(v, 0);   // row_shr:8
+    v += dpp_from<0x142, 0xA>(v, 0);   // row_bcast:15 -> rows 1 and 3
+    v += dpp_from<0x143, 0xC>(v, 0);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// maximum over the wave of non-negative values (every lane's result is only meaningful in lane 63: read it there)
+__device__ __forceinline__ int wave_max_nonneg(int v)
+{
+    v = max(v, dpp_from<0x111, 0xF>(v, 0));
+    v = max(v, dpp_from<0x112, 0xF>(v, 0));
+    v = max(v, dpp_from<0x114, 0xF>(v, 0));
+    v = max(v, dpp_from<0x118, 0xF>(v, 0));
+    v = max(v, dpp_from<0x142, 0xA>(v, 0));
+    v = max(v, dpp_from<0x143, 0xC>(v, 0));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // per strip: number of work items (0 without targets)
 __global__ __launch_bounds__(kBlock) void lane_items_count_kernel(GridParams g, const int *__restrict__ tstart, int Z,
                                                                   int per_item, int *__restrict__ nparts, i64 nstrips_total)
@@ -1950,11 +1984,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         {
             // (both prefix sums in one word -- a tile holds < 2^16 sources and the counts are clamped --: six dependent
             // shuffles instead of twelve; unsigned, so that the upper sum may use all of its 16 bits)
-            unsigned packed = (unsigned)cnt[0] | ((unsigned)cnt[1] << 16);
-            for (int d = 1; d < kWave; d <<= 1) {
-                const unsigned a = (unsigned)__shfl_up((int)packed, d);
-                if (lane >= d) packed += a;
-            }
+            const unsigned packed = (unsigned)wave_inclusive_sum((int)((unsigned)cnt[0] | ((unsigned)cnt[1] << 16)));
             const int incl0 = (int)(packed & 0xffffu), incl1 = (int)(packed >> 16);
             const int tot0 = __builtin_amdgcn_readlane(incl0, kWave - 1);
             nat_total = tot0 + __builtin_amdgcn_readlane(incl1, kWave - 1);
@@ -2033,11 +2063,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             // thin-layer starts: exclusive prefix over the bins, lane = thin layer (bins past NL are empty)
             {
                 const int c = s_hist[lane];
-                int incl = c;
-                for (int d = 1; d < kWave; d <<= 1) {
-                    const int a = __shfl_up(incl, d);
-                    if (lane >= d) incl += a;
-                }
+                const int incl = wave_inclusive_sum(c);
                 s_thin[lane] = incl - c;
                 if (lane == kWave - 1) s_thin[kWave] = incl;
             }
@@ -2074,22 +2100,22 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             int ei[NE];
             int rank[NE];
             bool hand_over;
-            // First with the narrow window (W thin layers either way); when any target of the round cannot be
-            // certified in it -- its k-th neighbour is farther than the window's faces, or the window holds too few
-            // sources: sparser places than the grid was laid out for -- the round is done again with a full cell
-            // layer either way, the guarantee of a 3x3x3 block.
-            for (int Wc = kRetry ? W : T;;) {
-            const int lo = max(tlz - Wc, 0), hi = min(tlz + Wc, NL - 1);
+            // First the narrow window (W thin layers either way).  When any target of the round cannot be certified
+            // in it -- its k-th neighbour is farther than the window's faces, or the window holds too few sources:
+            // sparser places than the grid was laid out for -- the scan goes on over what a full cell layer either
+            // way adds (the entries above and below what every lane has read already, into the same lists) and the
+            // round is certified against that window: the guarantee of a 3x3x3 block.
+            int lo = max(tlz - (kRetry ? W : T), 0), hi = min(tlz + (kRetry ? W : T), NL - 1);
             const int we = s_thin[hi + 1];
             int nsteps;
             {
                 // the longest window of the round: the trip count of every lane's scan (< 1024: the payload's 10 bits)
-                int wl = valid ? we - s_thin[lo] : 0;
-                for (int off = 32; off > 0; off >>= 1) wl = max(wl, __shfl_xor(wl, off));
-                nsteps = max((__builtin_amdgcn_readfirstlane(wl) + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll, kLaneUnroll);
+                const int wl = wave_max_nonneg(valid ? we - s_thin[lo] : 0);
+                nsteps = max((wl + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll, kLaneUnroll);
             }
             // every lane reads nsteps entries ending at its window's end (or starting at the tile's start)
             const int wbase = max(we - nsteps, 0);
+            int ext_hi = 0, ext_lo = 0;   // (wave-uniform) entries read behind / before [wbase, wbase + nsteps) so far
             float d[L];
 #pragma unroll
             for (int s = 0; s < L; ++s) d[s] = 3.0e38f;
@@ -2134,12 +2160,17 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             asm volatile("" ::"v"(d[0]), "v"(d[L - 1]));
 #endif
             MM_STAMP(4);   // scan
+            for (int attempt = 0;; ++attempt) {
             // ---- exact fp64 distance (reference arithmetic) and source id of the K + 1 best keys
             {
                 int pos[NE];
 #pragma unroll
-                for (int e = 0; e < NE; ++e)
-                    pos[e] = __float_as_int(wp[min((int)(__float_as_uint(d[e]) & 1023u), nsteps - 1)].w);
+                for (int e = 0; e < NE; ++e) {
+                    // slot -> tile entry: [0, nsteps) the first scan, then the entries behind it, then those before it
+                    const int slot = (int)(__float_as_uint(d[e]) & 1023u);
+                    const int idx = slot < nsteps + ext_hi ? wbase + slot : wbase - ext_lo + (slot - nsteps - ext_hi);
+                    pos[e] = __float_as_int(tile[min((unsigned)idx, (unsigned)nat_total)].w);   // (sentinel keys: any entry)
+                }
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     const double2 *r2 = reinterpret_cast<const double2 *>(sorted_xyz + (i64)max(pos[e], 0) * kRec);
@@ -2243,8 +2274,35 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 if (hi < NL - 1 || zb < g.nz - 1) bound = fmin(bound, (((double)zbase + (double)(hi + 1) * th) - (double)tz) - zs);
                 if (bound < INFINITY && !(bound > 0.0 && kth < bound * bound)) hand_over = true;
             }
-            if (!kRetry || Wc >= T || !__any(valid && hand_over)) break;
-            Wc = T;
+            if (!kRetry || attempt > 0 || W >= T || !__any(valid && hand_over)) break;
+            // ---- widen to a full cell layer either way: scan what that adds to each side of the entries already read
+            lo = max(tlz - T, 0);
+            hi = min(tlz + T, NL - 1);
+            {
+                const int need_hi = wave_max_nonneg(valid ? max(s_thin[hi + 1] - (wbase + nsteps), 0) : 0);
+                const int need_lo = wave_max_nonneg(valid ? max(wbase - s_thin[lo], 0) : 0);
+                ext_hi = (need_hi + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll;
+                ext_lo = (need_lo + kLaneUnroll - 1) / kLaneUnroll * kLaneUnroll;
+            }
+            if (nsteps + ext_hi + ext_lo > 1023) {   // (the payload has 10 bits: such a tile's targets are handed over)
+                ext_hi = ext_lo = 0;
+                break;
+            }
+            // (entries beyond the tile's ends read as its far-away padding entry)
+            for (int j = 0; j < ext_hi + ext_lo; j += kLaneUnroll) {
+                const int first = j < ext_hi ? wbase + nsteps + j : wbase - ext_lo + (j - ext_hi);
+                float4 q[kLaneUnroll];
+#pragma unroll
+                for (int u = 0; u < kLaneUnroll; ++u) q[u] = tile[min((unsigned)(first + u), (unsigned)nat_total)];
+#pragma unroll
+                for (int u = 0; u < kLaneUnroll; ++u) {
+                    const float fx = q[u].x - tx, fy = q[u].y - ty, fz = q[u].z - tz;
+                    const float d2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                    float key;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d2), "v"(key_mask), "s"(nsteps + j + u));
+                    lane_list_insert<L>(d, key, neg_inf);
+                }
+            }
             }   // (attempts)
             if (dist_out && valid && !hand_over) {
 #pragma unroll
