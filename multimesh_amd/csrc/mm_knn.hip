@@ -1854,37 +1854,85 @@ __device__ __forceinline__ int wave_max_nonneg(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// per strip: number of work items (0 without targets)
-__global__ __launch_bounds__(kBlock) void lane_items_count_kernel(GridParams g, const int *__restrict__ tstart, int Z,
-                                                                  int per_item, int *__restrict__ nparts, i64 nstrips_total)
-{
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nstrips_total) return;
-    const int nstrips = (g.nz + Z - 1) / Z;
-    const int col = (int)(t / nstrips), strip = (int)(t - (i64)col * nstrips);
-    const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
-    const int tn = tstart[col * g.nz + cz1] - tstart[col * g.nz + cz0];
-    nparts[t] = (tn + per_item - 1) / per_item;
-}
-
 // Item q of the list (strips in spatial order) is stored at slot 8 m + x, x = the eighth of the list it lies in,
 // m = its place inside that eighth: workgroup b of the lane kernel simply takes slot b -- workgroups are dealt
 // round-robin over the 8 XCDs, so XCD x walks the x-th eighth of the list, a contiguous piece of space (its L2
 // sees each source about once), and the workgroup's first load depends on nothing but its own index.  Slots
 // without an item stay at -1 (the array is pre-set).
-__global__ __launch_bounds__(kBlock) void lane_items_fill_kernel(const int *__restrict__ item_start, i64 nstrips_total,
-                                                                 int2 *__restrict__ items)
+// The list is made in THREE dispatches (it used to take six: count, three scan kernels, a fill of the slots, the fill of the
+// items): the per-strip item counts are recomputed from the targets' cell starts wherever they are needed.
+__device__ __forceinline__ int lane_strip_parts(const GridParams &g, const int *__restrict__ tstart, int Z, int per_item,
+                                                i64 t, i64 nstrips_total)
 {
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nstrips_total) return;
-    const int a = item_start[t], b = item_start[t + 1];
-    const i64 total = item_start[nstrips_total];
-    for (int q = a; q < b; ++q) {
-        int x = (int)(((i64)q * 8) / total);
-        while (x > 0 && (i64)q < ((total * x) >> 3)) --x;
-        while (x < 7 && (i64)q >= ((total * (x + 1)) >> 3)) ++x;
-        const i64 m = (i64)q - ((total * x) >> 3);
-        items[8 * m + x] = make_int2((int)t, q - a);
+    if (t >= nstrips_total) return 0;
+    const int nstrips = (g.nz + Z - 1) / Z;
+    const int col = (int)(t / nstrips), strip = (int)(t - (i64)col * nstrips);
+    const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
+    const int tn = tstart[col * g.nz + cz1] - tstart[col * g.nz + cz0];
+    return (tn + per_item - 1) / per_item;
+}
+
+// (1) per tile of kScanTile strips: the number of items; every slot of the list is pre-set to "no item" on the way
+__global__ __launch_bounds__(kBlock) void lane_items_sums_kernel(GridParams g, const int *__restrict__ tstart, int Z,
+                                                                 int per_item, i64 nstrips_total, int *__restrict__ tile_sums,
+                                                                 int2 *__restrict__ items, i64 nslots)
+{
+    const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    int sum = 0;
+    for (int q = 0; q < kScanItems; ++q) sum += lane_strip_parts(g, tstart, Z, per_item, base + q, nstrips_total);
+    int total;
+    (void)block_exclusive_scan(sum, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+    for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < nslots; q += (i64)gridDim.x * blockDim.x)
+        items[q] = make_int2(-1, -1);
+}
+
+// (2) single block: exclusive scan of the tile sums, the grand total behind them
+__global__ __launch_bounds__(kBlock) void lane_items_offsets_kernel(int *__restrict__ tile_sums, int ntiles)
+{
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const int v = i < ntiles ? tile_sums[i] : 0;
+        int total;
+        const int excl = block_exclusive_scan(v, &total);
+        const int c = carry;
+        if (i < ntiles) tile_sums[i] = c + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+}
+
+// (3) every strip's items into their slots (the slot rule above)
+__global__ __launch_bounds__(kBlock) void lane_items_place_kernel(GridParams g, const int *__restrict__ tstart, int Z,
+                                                                  int per_item, i64 nstrips_total,
+                                                                  const int *__restrict__ tile_sums, int ntiles,
+                                                                  int2 *__restrict__ items)
+{
+    const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    int np[kScanItems];
+    int sum = 0;
+    for (int q = 0; q < kScanItems; ++q) {
+        np[q] = lane_strip_parts(g, tstart, Z, per_item, base + q, nstrips_total);
+        sum += np[q];
+    }
+    int block_total;
+    int a = block_exclusive_scan(sum, &block_total) + tile_sums[blockIdx.x];
+    const i64 total = tile_sums[ntiles];
+    for (int q = 0; q < kScanItems; ++q) {
+        for (int part = 0; part < np[q]; ++part) {
+            const i64 it = (i64)a + part;
+            int x = (int)((it * 8) / total);
+            while (x > 0 && it < ((total * x) >> 3)) --x;
+            while (x < 7 && it >= ((total * (x + 1)) >> 3)) ++x;
+            const i64 m = it - ((total * x) >> 3);
+            items[8 * m + x] = make_int2((int)(base + q), part);
+        }
+        a += np[q];
     }
 }
 
@@ -2397,9 +2445,7 @@ struct LaneWork {
     int sorted_rows;     // rows and hand-overs by position in the cell-sorted order
     i64 nstrips_total;   // columns x strips per column
     i64 max_items;       // upper bound on the work items: strips + targets / (64 * kLaneRounds)
-    int *nparts;         // [nstrips_total + 1]
-    int *item_start;     // [nstrips_total + 1]; the last entry is the number of items
-    int *tile_sums;
+    int *tile_sums;      // [tiles of strips + 1]: exclusive item offsets per tile, then the number of items
     int2 *items;         // [max_items]
 };
 
@@ -2511,13 +2557,12 @@ void launch_fast(mm_context *ctx, const mm_knn_index *ix, const GridParams &g, c
         // round 2's kernel: work items from the strips that hold targets, then one lane per target
         constexpr int KL = K <= kLaneMaxK ? K : 1;   // (the strip-only list lengths are never instantiated)
         const int per_item = kWave * kLaneRounds;
-        const unsigned gs = (unsigned)((lane->nstrips_total + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(lane_items_count_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, g, tstart, lane->Z, per_item,
-                           lane->nparts, lane->nstrips_total);
-        (void)mm_exclusive_scan_int(ctx, lane->nparts, lane->nstrips_total, lane->item_start, lane->tile_sums);
-        (void)hipMemsetAsync(lane->items, 0xff, (size_t)lane->max_items * sizeof(int2), ctx->stream);   // -1: no item
-        hipLaunchKernelGGL(lane_items_fill_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, lane->item_start,
-                           lane->nstrips_total, lane->items);
+        const int ntiles = (int)((lane->nstrips_total + kScanTile - 1) / kScanTile);
+        hipLaunchKernelGGL(lane_items_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, g, tstart, lane->Z, per_item,
+                           lane->nstrips_total, lane->tile_sums, lane->items, lane->max_items);
+        hipLaunchKernelGGL(lane_items_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, lane->tile_sums, ntiles);
+        hipLaunchKernelGGL(lane_items_place_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, g, tstart, lane->Z, per_item,
+                           lane->nstrips_total, lane->tile_sums, ntiles, lane->items);
         const i64 wgs = lane->max_items;   // one workgroup per slot (a multiple of 8; < 2^31: npts and the strip count are)
         if (record_stage) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
         hipLaunchKernelGGL((knn_lane_kernel<KL, IDX>), dim3((unsigned)wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc,
@@ -2886,7 +2931,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                 mm_round256((size_t)nt * sizeof(int)) + 256;
         ++nlevels;
     }
-    need += mm_round256((size_t)npts * sizeof(int)) + 256;           // stragglers of all levels (one list)
+    need += mm_round256((size_t)npts * sizeof(int)) + 256 * (size_t)(2 + nlevels);   // stragglers of all levels (one list), counters
     // One lane per target (knn_lane_kernel) when there is a single grid that is deep in z, the lists are
     // short and there are enough targets per cell to fill 64-lane rounds; otherwise the strip / cell kernels.
     // MM_KNN_KERNEL=lane|strip|cell forces a kernel (tuning and tests only).
@@ -2919,29 +2964,27 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         lane_work.nstrips_total = (i64)ix->dims[0] * ix->dims[1] * nstrips;
         // (slots: 8 per row of the permuted list, so up to 7 more than items; a multiple of 8 = the grid)
         lane_work.max_items = (lane_work.nstrips_total + npts / (kWave * kLaneRounds) + 16 + 7) / 8 * 8;
-        need += 2 * mm_round256((size_t)(lane_work.nstrips_total + 1) * sizeof(int)) +
-                mm_round256((size_t)((lane_work.nstrips_total + kScanTile) / kScanTile) * sizeof(int)) +
+        need += mm_round256((size_t)((lane_work.nstrips_total + kScanTile) / kScanTile + 2) * sizeof(int)) +
                 mm_round256((size_t)lane_work.max_items * sizeof(int2)) + 1024;
     }
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) return rc;
     int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
-    int *fb_count = (int *)mm_scratch_take(ctx, 256);
+    // (one block, zeroed by ONE fill: the stragglers' counter, then every level's {passed down, strips} counters)
+    int *fb_count = (int *)mm_scratch_take(ctx, 256 * (size_t)(1 + nlevels));
     if (!fb_list || !fb_count) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
     if (use_lane) {
-        lane_work.nparts = (int *)mm_scratch_take(ctx, (size_t)(lane_work.nstrips_total + 1) * sizeof(int));
-        lane_work.item_start = (int *)mm_scratch_take(ctx, (size_t)(lane_work.nstrips_total + 1) * sizeof(int));
-        lane_work.tile_sums = (int *)mm_scratch_take(ctx, (size_t)((lane_work.nstrips_total + kScanTile) / kScanTile) * sizeof(int));
+        lane_work.tile_sums = (int *)mm_scratch_take(ctx, (size_t)((lane_work.nstrips_total + kScanTile) / kScanTile + 2) * sizeof(int));
         lane_work.items = (int2 *)mm_scratch_take(ctx, (size_t)lane_work.max_items * sizeof(int2));
-        if (!lane_work.nparts || !lane_work.item_start || !lane_work.tile_sums || !lane_work.items) {
+        if (!lane_work.tile_sums || !lane_work.items) {
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
     }
-    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), ctx->stream));
+    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 256 * (size_t)(1 + nlevels), ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
     const int *list = nullptr, *list_count = nullptr;   // level 0: every target
     int level = 0;
@@ -2956,8 +2999,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
-        int *down_count = (int *)mm_scratch_take(ctx, 256);
-        int *strip_count = down_count ? down_count + 1 : nullptr;
+        int *down_count = fb_count + 64 * (1 + level);
+        int *strip_count = down_count + 1;
         unsigned *strip_list = level > 0 ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
         double *tsorted = nullptr;
         if (sorted_rows) {
@@ -2974,7 +3017,6 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             return MM_ERR_ALLOC;
         }
         MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
-        MM_HIP_CHECK(hipMemsetAsync(down_count, 0, 2 * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);

@@ -60,20 +60,25 @@ __device__ __forceinline__ double map_axis(const double (&v)[8], double hr, doub
 
 // Newton inversion (trilinearinterpolator.c:260-305).  x/y/z hold the corner coordinates per
 // axis.  Returns true when converged; xi receives the last iterate either way.
+// first_it > 0 CONTINUES a solve: xi holds the iterate after first_it updates (the iteration is a deterministic map
+// of the iterate, so running trips [0, a) and later [a, b) gives the iterates of [0, b)); trips first_it .. max_it - 1.
 __device__ __forceinline__ bool newton_hex8(const double px, const double py, const double pz,
                                             const double (&x)[8], const double (&y)[8],
-                                            const double (&z)[8], double (&xi)[3], const int max_it = 50)
+                                            const double (&z)[8], double (&xi)[3], const int max_it = 50,
+                                            const int first_it = 0)
 {
-    xi[0] = 0.;
-    xi[1] = 0.;
-    xi[2] = 0.;
+    if (first_it == 0) {
+        xi[0] = 0.;
+        xi[1] = 0.;
+        xi[2] = 0.;
+    }
     const double sx = fabs(x[1] - x[0]);
     const double sy = fabs(y[1] - y[0]);
     const double sz = fabs(z[1] - z[0]);
     const double sxy = sx > sy ? sx : sy;
     const double scale = sz > sxy ? sz : sxy;
     const double tol = 1e-8 * scale;
-    for (int it = 0; it < max_it; ++it) {
+    for (int it = first_it; it < max_it; ++it) {
         const double hr = 0.5 * (xi[0] + 1.0);
         const double hs = 0.5 * (xi[1] + 1.0);
         const double ht = 0.5 * (xi[2] + 1.0);
@@ -159,28 +164,32 @@ __device__ __forceinline__ void weights_hex8(const double (&xi)[3], double (&w)[
     }
 }
 
-struct Corners {
-    i64 id[8];
+// ID: i64 as the arrays hold them, or int where the caller has checked that node ids fit (half the registers: the
+// pass kernel keeps the ids across the Newton solve)
+template <typename ID>
+struct CornersT {
+    ID id[8];
     double x[8], y[8], z[8];
 };
+typedef CornersT<i64> Corners;
 
-template <bool EXODUS>
+template <bool EXODUS, typename ID>
 __device__ __forceinline__ void load_corners(const i64 *__restrict__ conn,
-                                             const double *__restrict__ nodes, i64 elem, Corners &c)
+                                             const double *__restrict__ nodes, i64 elem, CornersT<ID> &c)
 {
     const longlong2 *row = reinterpret_cast<const longlong2 *>(conn + elem * 8);
     const longlong2 a = row[0], b = row[1], cc = row[2], d = row[3];
-    c.id[0] = a.x;
-    c.id[1] = EXODUS ? b.y : a.y;  // reference scripts/cli.py:79-81: columns 1 and 3 swap
-    c.id[2] = b.x;
-    c.id[3] = EXODUS ? a.y : b.y;
-    c.id[4] = cc.x;
-    c.id[5] = cc.y;
-    c.id[6] = d.x;
-    c.id[7] = d.y;
+    c.id[0] = (ID)a.x;
+    c.id[1] = (ID)(EXODUS ? b.y : a.y);  // reference scripts/cli.py:79-81: columns 1 and 3 swap
+    c.id[2] = (ID)b.x;
+    c.id[3] = (ID)(EXODUS ? a.y : b.y);
+    c.id[4] = (ID)cc.x;
+    c.id[5] = (ID)cc.y;
+    c.id[6] = (ID)d.x;
+    c.id[7] = (ID)d.y;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        const double *p = nodes + c.id[n] * 3;
+        const double *p = nodes + (i64)c.id[n] * 3;
         c.x[n] = p[0];
         c.y[n] = p[1];
         c.z[n] = p[2];
@@ -216,14 +225,15 @@ struct Emit {
     double *out;            // [npoints][ncomp]
 };
 
-__device__ __forceinline__ void emit_row(const Emit &em, i64 i, const i64 (&id)[8], const double (&wt)[8])
+template <typename ID>
+__device__ __forceinline__ void emit_row(const Emit &em, i64 i, const ID (&id)[8], const double (&wt)[8])
 {
     if (em.enc) {
         longlong2 *e2 = reinterpret_cast<longlong2 *>(em.enc + i * 8);
         double2 *w2 = reinterpret_cast<double2 *>(em.w + i * 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            e2[q] = make_longlong2(id[2 * q], id[2 * q + 1]);
+            e2[q] = make_longlong2((i64)id[2 * q], (i64)id[2 * q + 1]);
             w2[q] = make_double2(wt[2 * q], wt[2 * q + 1]);
         }
     }
@@ -231,7 +241,7 @@ __device__ __forceinline__ void emit_row(const Emit &em, i64 i, const i64 (&id)[
         i64 sid[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n)
-            sid[n] = (unsigned long long)id[n] < (unsigned long long)em.nnodes ? id[n] : 0;
+            sid[n] = (unsigned long long)(i64)id[n] < (unsigned long long)em.nnodes ? (i64)id[n] : 0;
         for (int c = 0; c < em.ncomp; ++c) {
             const double *f = em.fields + (i64)c * em.nnodes;
             double p[8];
@@ -347,6 +357,9 @@ constexpr int kRefIters = 50;               // the reference's own cap (trilinea
 // same verdict) in a round where slow solves only keep each other company.  "Not converged" under
 // the reference's cap rejects the candidate, as in the reference.
 constexpr int kPassBlock = 256;
+#ifndef MM_PASS_WAVES   // tuning builds only: minimum waves per SIMD the register allocator must leave room for
+#define MM_PASS_WAVES 2
+#endif
 // LDS entries per wave and queue.  A full queue (>= 64 waiting) is served before anything is added to it, the
 // slowest tier first: tiers 1 and 2 only grow in rounds of the tier below, which run while they hold fewer
 // than 64 (< 128 after the round); tier 0 grows in every round -- 63 + 64 from its own rounds, then one
@@ -386,8 +399,10 @@ __device__ unsigned long long g_loc_stamps[kLocStampSlots * 8];
 // the same order: a wave's 64 targets are 8 neighbouring grid cells -- coordinates and rows stream, and the
 // lanes share their candidate elements' connectivity rows and nodes.  i is then the position in that order
 // (points, rows, queues), the target's own index (outputs, reference-order list) comes out of its record.
-template <bool EXODUS, typename IDX, bool SORTED>
-__global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoints,
+// NID: the type node ids are held in across a solve -- int when the caller knows the mesh has fewer than 2^31 nodes
+// (the fused pipeline does), i64 as the connectivity array stores them otherwise.
+template <bool EXODUS, typename IDX, bool SORTED, typename NID>
+__global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(i64 k, i64 npoints,
                                                                  const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  Emit em,
@@ -399,10 +414,13 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
     // [wave][tier][entry]: tier 0 ordinary retries, 1 solves that outlasted kPassIters, 2 ... kMidIters
     __shared__ int2 s_queue0[kPassBlock / 64][kWaveQueue0];
     __shared__ int2 s_queue12[kPassBlock / 64][2][kWaveQueue];
+    __shared__ double s_qxi[kPassBlock / 64][2][3][kWaveQueue];   // ... and the iterate their solve stopped at
     const int lane = threadIdx.x & 63;
     int2 *const my_q0 = s_queue0[threadIdx.x >> 6];
     int2 *const my_q1 = s_queue12[threadIdx.x >> 6][0];
     int2 *const my_q2 = s_queue12[threadIdx.x >> 6][1];
+    double (*const my_xi1)[kWaveQueue] = s_qxi[threadIdx.x >> 6][0];
+    double (*const my_xi2)[kWaveQueue] = s_qxi[threadIdx.x >> 6][1];
     int held0 = 0, held1 = 0, held2 = 0;   // wave-uniform: entries waiting in each tier's queue
 
     // XCD-aware deal of the fresh batches.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         bool active;
         i64 i = 0;
         int j = 0;
+        double xi_in[3] = {0., 0., 0.};   // tiers 1 and 2: the iterate the solve stopped at under the tier below's cap
         int tier = 0;          // whose cap this round's solves run under
         int lgG = 0;           // log2 of the lanes per target (only the drain rounds work ahead)
         if (held2 >= 64 || held1 >= 64 || held0 >= 64) {
@@ -447,6 +466,12 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             i = e.x;
             j = e.y;
             active = true;
+            if (tier > 0) {
+                double (*const qx)[kWaveQueue] = tier == 1 ? my_xi1 : my_xi2;
+                xi_in[0] = qx[0][from + lane];
+                xi_in[1] = qx[1][from + lane];
+                xi_in[2] = qx[2][from + lane];
+            }
         } else if (next < total) {
             const i64 q = next + lane;
             active = q < total;
@@ -475,6 +500,10 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
                 const int2 e = (tier == 1 ? my_q1 : my_q2)[lane];
                 i = e.x;
                 j = e.y;
+                double (*const qx)[kWaveQueue] = tier == 1 ? my_xi1 : my_xi2;
+                xi_in[0] = qx[0][lane];
+                xi_in[1] = qx[1][lane];
+                xi_in[2] = qx[2][lane];
             }
             if (tier == 1) held1 = 0;
             else held2 = 0;
@@ -486,7 +515,7 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
         // outcome of this lane's candidate: 0 rejected, 1 accepted, 2 too slow for this cap (next tier),
         // 3 no candidate left
         int outcome = 0;
-        Corners c;
+        CornersT<NID> c;
         double wt[8];
         MM_LSTAMP(0);   // round selection, queue reads
         i64 tid = i;   // the target's own index
@@ -543,8 +572,13 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             if (j >= k) {
                 outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
             } else if (have) {
-                double xi[3];
-                const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap);
+                double xi[3] = {xi_in[0], xi_in[1], xi_in[2]};
+                // (a tier's solves start where the tier below's cap stopped them: trips [first, cap))
+                const int first = tier == 0 ? 0 : (tier == 1 ? kPassIters : kMidIters);
+                const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap, first);
+                xi_in[0] = xi[0];
+                xi_in[1] = xi[1];
+                xi_in[2] = xi[2];
 #ifdef MM_LOCATE_STAMPS
                 asm volatile("" ::"v"(xi[0]), "v"(xi[2]));
                 MM_LSTAMP(3);   // Newton
@@ -594,8 +628,14 @@ __global__ __launch_bounds__(kPassBlock) void locate_pass_kernel(i64 k, i64 npoi
             // under tier 0's cap, so its slow solves go to tier 1 like everybody else's)
             const int up = tier == 0 ? 1 : 2;
             const unsigned long long svote = __ballot(slower);
-            if (slower)
-                (up == 1 ? my_q1 + held1 : my_q2 + held2)[__popcll(svote & ((1ull << lane) - 1ull))] = make_int2((int)i, j);
+            if (slower) {
+                const int at = (up == 1 ? held1 : held2) + __popcll(svote & ((1ull << lane) - 1ull));
+                (up == 1 ? my_q1 : my_q2)[at] = make_int2((int)i, j);
+                double (*const qx)[kWaveQueue] = up == 1 ? my_xi1 : my_xi2;
+                qx[0][at] = xi_in[0];
+                qx[1][at] = xi_in[1];
+                qx[2][at] = xi_in[2];
+            }
             if (up == 1) held1 += __popcll(svote);
             else held2 += __popcll(svote);
         }
@@ -640,7 +680,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     i64 resident = 0;
     {
         int per_cu = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, false>, kPassBlock, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, true, int>, kPassBlock, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         if (e != hipSuccess || per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
@@ -658,18 +698,25 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         dim3 g_((unsigned)grid), b_(block);
         // (tsorted: rows nn[] and the records are in the kNN stage's cell-sorted order; the reference-order kernel
         // below works on the targets' own indices either way)
-        if (tsorted && conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, true>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                               em, nodes, tsorted, slow, slow_count);
-        else if (tsorted)
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, true>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                               em, nodes, tsorted, slow, slow_count);
-        else if (conn_is_exodus)
-            hipLaunchKernelGGL((locate_pass_kernel<true, IDX, false>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                               em, nodes, pts, slow, slow_count);
-        else
-            hipLaunchKernelGGL((locate_pass_kernel<false, IDX, false>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem,
-                               em, nodes, pts, slow, slow_count);
+        // (node ids in 32 bits when the caller has told us how many nodes there are: fewer registers across the solve)
+        const bool nid32 = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
+#define MM_PASS_LAUNCH(EX, SO, NID, P)                                                                                  \
+    hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, SO, NID>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, \
+                       nodes, P, slow, slow_count)
+        if (tsorted && conn_is_exodus) {
+            if (nid32) MM_PASS_LAUNCH(true, true, int, tsorted);
+            else MM_PASS_LAUNCH(true, true, i64, tsorted);
+        } else if (tsorted) {
+            if (nid32) MM_PASS_LAUNCH(false, true, int, tsorted);
+            else MM_PASS_LAUNCH(false, true, i64, tsorted);
+        } else if (conn_is_exodus) {
+            if (nid32) MM_PASS_LAUNCH(true, false, int, pts);
+            else MM_PASS_LAUNCH(true, false, i64, pts);
+        } else {
+            if (nid32) MM_PASS_LAUNCH(false, false, int, pts);
+            else MM_PASS_LAUNCH(false, false, i64, pts);
+        }
+#undef MM_PASS_LAUNCH
     }
     mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     // out of candidates without an acceptance: reference-order kernel
