@@ -57,6 +57,7 @@ constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a den
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
+constexpr int kBoxSlot = 48;   // six doubles of the pinned h_counters receive the sources' bounding box
 
 struct GridParams {
     int nx, ny, nz;
@@ -106,28 +107,39 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const double *__re
     }
 }
 
-__global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
-                                                         double *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
+                                                             double *__restrict__ out)
 {
-    // one wave per component (grid 6): lanes stride over the per-block partials, four independent loads in
-    // flight each, then a butterfly reduction
+    // one workgroup per component (grid 6): the threads stride over the per-block partials -- eight independent
+    // loads in flight each for the fused pipeline's 2048 partials: ONE round trip (a single wave walking them took
+    // 35 us of an otherwise idle GPU in mid-step) --, then a butterfly per wave and four values through LDS
+    __shared__ double s_part[kBlock / 64];
     const int a = blockIdx.x;
     const double init = a < 3 ? INFINITY : -INFINITY;
-    double v[4] = {init, init, init, init};
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
+    double v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int bb = b + 64 * u;
+    for (int u = 0; u < 8; ++u) v[u] = init;
+    for (int b = threadIdx.x; b < nblocks; b += 8 * kBlock) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int bb = b + kBlock * u;
             const double p = bb < nblocks ? partial[bb * 6 + a] : init;
             v[u] = a < 3 ? fmin(v[u], p) : fmax(v[u], p);
         }
     }
-    double r = a < 3 ? fmin(fmin(v[0], v[1]), fmin(v[2], v[3])) : fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+    double r = init;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r = a < 3 ? fmin(r, v[u]) : fmax(r, v[u]);
     for (int off = 32; off > 0; off >>= 1) {
         const double o = __shfl_xor(r, off);
         r = a < 3 ? fmin(r, o) : fmax(r, o);
     }
-    if (threadIdx.x == 0) out[a] = r;
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < kBlock / 64; ++wv) r = a < 3 ? fmin(r, s_part[wv]) : fmax(r, s_part[wv]);
+        out[a] = r;
+    }
 }
 
 // ---- cell assignment ----------------------------------------------------------------
@@ -2793,7 +2805,8 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         }
         const double sparse_count = (double)ctx->h_counters[kStatSlot + kMaxLevels - 1] * (double)(1 << sample_shift);
         if (sparse_share) *sparse_share = sparse_count / (double)nsrc;
-        if (getenv("MM_KNN_DEBUG")) {
+        static const bool dbg_build = getenv("MM_KNN_DEBUG") != nullptr;
+        if (dbg_build) {
             fprintf(stderr, "[mm_knn] build: %lld cells; %% of the sources in cells of at most %d: %.1f, above", (long long)ncells,
                     kSparseCount, 100.0 * sparse_count / (double)nsrc);
             for (int b = 0; b < kMaxLevels - 1; ++b)
@@ -2820,18 +2833,21 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
         if (box_partial_d) {
             // the producer of the sources (the fused pipeline's centroid kernel) already left partials
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(64), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
         } else {
             hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
                                (int)ndim, partial);
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(64), 0, ctx->stream, partial, nblocks, d_box);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, partial, nblocks, d_box);
         }
-        hipError_t e = hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
+        // (into the context's pinned mirror: a pageable destination goes through the runtime's staging path)
+        double *h_box = reinterpret_cast<double *>(ctx->h_counters + kBoxSlot);
+        hipError_t e = hipMemcpyAsync(h_box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_HIP, "bounding box: %s", hipGetErrorString(e));
             return MM_ERR_HIP;
         }
+        for (int q = 0; q < 6; ++q) box[q] = h_box[q];
     }
     // grid resolution: ~per_cell sources per cell over the axes that have extent
     // (MM_KNN_PER_CELL overrides the default, for tuning experiments only)
@@ -2944,9 +2960,12 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     if (!force_kernel && lane_level0 && ix->fine && ix->dims[2] >= 6 && k <= 8 && npts >= 2 * ix->ncells) use_lane = true;
     if (force_kernel) use_lane = strcmp(force_kernel, "lane") == 0 && !ix->fine && ix->dims[2] >= 2 && k <= kLaneMaxK;
     // MM_KNN_FORCE_LIST: every target through the list-mode kernel (tests of that kernel only)
-    const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;   // (read per call: a test sets it)
+    // (MM_KNN_FORCE_LIST here and MM_KNN_LEVELS / MM_KNN_PER_CELL in the build are read per call on purpose: tests switch them
+    // inside one process; every other knob is read once)
+    const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;
     if (force_list) use_lane = false;
-    const bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !getenv("MM_KNN_UNSORTED_ROWS");
+    static const bool unsorted_rows = getenv("MM_KNN_UNSORTED_ROWS") != nullptr;
+    const bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !unsorted_rows;
     lane_work.sorted_rows = sorted_rows ? 1 : 0;
     if (use_lane) {
         static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
@@ -3037,7 +3056,8 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         else MM_FAST(32);
 #undef MM_FAST
         MM_HIP_CHECK(hipGetLastError());
-        if (getenv("MM_KNN_DEBUG")) {
+        static const bool dbg_query = getenv("MM_KNN_DEBUG") != nullptr;
+        if (dbg_query) {
             int h[2] = {0, 0};
             MM_HIP_CHECK(hipMemcpyAsync(h, fb_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             MM_HIP_CHECK(hipMemcpyAsync(h + 1, down_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

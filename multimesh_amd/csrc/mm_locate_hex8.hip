@@ -743,7 +743,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                                nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
     }
     MM_HIP_CHECK(hipGetLastError());
-    if (getenv("MM_LOCATE_DEBUG")) {
+    static const bool dbg_locate = getenv("MM_LOCATE_DEBUG") != nullptr;
+    if (dbg_locate) {
         // diagnostic: sizes of the pass queues and of the reference-order list (synchronises)
         int h[16];
         MM_HIP_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
