@@ -122,7 +122,7 @@ def gll_bytes(n_targets, n_elem, P, dim, k, ncomp):
 #: rocprofv3 --kernel-trace prints for them (profiles/*_kernel_stats.csv)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
 KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_lane_kernel<8, int>",
-                   "locate_pass0": "locate_pass_kernel<true, int, true>", "gather": "gather8_kernel<true>"}
+                   "locate_pass0": "locate_pass_kernel<true, int, true, int>", "gather": "gather8_kernel<true>"}
 #: what the counters say limits each of them: the two big kernels sit on the vector-issue
 #: floor, the streaming ones on HBM
 BOUND_OF_STAGE = {"centroid": "hbm", "knn_cell": "valu", "locate_pass0": "valu", "gather": "hbm"}

@@ -57,6 +57,7 @@ constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a den
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
+static_assert(kMaxLevels <= 16, "the level statistic has 16 counter slots");
 constexpr int kBoxSlot = 48;   // six doubles of the pinned h_counters receive the sources' bounding box
 
 struct GridParams {
@@ -2752,7 +2753,8 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         free_index(ix);
         return MM_ERR_ALLOC;
     }
-    e = hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream);
+    // (whole 256-byte units -- the carve is rounded up to them --: an odd tail costs a second fill dispatch)
+    e = hipMemsetAsync(counts, 0, mm_round256((size_t)(ncells + 1) * sizeof(int)), ctx->stream);
     if (e != hipSuccess) { mm_set_error(MM_ERR_HIP, "memset: %s", hipGetErrorString(e)); free_index(ix); return MM_ERR_HIP; }
     const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
     if (nsrc > 0)
@@ -2763,7 +2765,7 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     if (level_extra) *level_extra = 0;
     if (want_stat) {
         i64 *stat = ctx->d_counters + kStatSlot;
-        e = hipMemsetAsync(stat, 0, kMaxLevels * sizeof(i64), ctx->stream);
+        e = hipMemsetAsync(stat, 0, 16 * sizeof(i64), ctx->stream);   // (slots kStatSlot .. +15 are the statistic's)
         if (e == hipSuccess) {
             hipLaunchKernelGGL(level_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                                ctx->stream, counts, ncells, (unsigned long long *)stat, sample_shift);
@@ -3035,7 +3037,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
-        MM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), ctx->stream));
+        MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_round256((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);

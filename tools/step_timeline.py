@@ -1,11 +1,15 @@
 """Timeline of ONE hot-path step from a rocprofv3 kernel trace (csv): per dispatch its start relative to the
-step's first kernel, its duration and the idle gap since the previous dispatch ended.  The step is the last
-run of dispatches that begins with the centroid kernel.   usage: step_timeline.py <dir with *kernel_trace.csv>"""
+step's first kernel, its duration and the idle gap since the previous dispatch ended.  The step is the shortest
+run of dispatches between two centroid kernels.   usage: step_timeline.py <dir with *kernel_trace.csv>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "centroid_bbox_kernel" in r["Kernel_Name"]]
-a = starts[-2]; b = starts[-1]            # the last complete step
+# the SHORTEST run between two centroid kernels: a plain timed step (the bench also runs the pipeline with the operator
+# written out and from host arrays, which allocate in mid-step)
+spans = [(int(rows[starts[q + 1] - 1]["End_Timestamp"]) - int(rows[starts[q]]["Start_Timestamp"]), q) for q in range(len(starts) - 1)]
+q = min(spans)[1]
+a, b = starts[q], starts[q + 1]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"]); prev_end = t0; busy = 0; gaps = 0
 for r in step:
