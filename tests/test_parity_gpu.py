@@ -723,6 +723,51 @@ def test_knn_lane_kernel_next_to_a_cell_with_more_than_65535_sources(ctx, k):
     assert np.array_equal(idx, O.knn_ckdtree(src, q, k, workers=-1)[0])
 
 
+_LANE_WINDOW_CHECK = r"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from multimesh_amd import synth
+from multimesh_amd.device import Context
+from oracle import oracle as O
+ctx = Context(0)
+rng = np.random.default_rng(33)
+# (a) mesh-like: centroids of a jittered hex mesh, targets = nodes of another one + random points; (b) a random cloud
+pa, ca = synth.hex_mesh(61, seed=1)
+cen = O.centroid(ca, pa)
+pb, _ = synth.hex_mesh(70, seed=7)
+for src, q in ((cen, np.concatenate([pb, rng.uniform(-0.05, 1.05, size=(150_000, 3))])),
+               (rng.uniform(size=(300_000, 3)), rng.uniform(-0.02, 1.02, size=(600_000, 3)))):
+    tree = ctx.knn_build(src)
+    for k in (1, 4, 8):
+        idx, dist = tree.query(q, k, want_dist=True)
+        ref, refd = O.knn_ckdtree(src, q, k, workers=-1)
+        assert np.array_equal(idx.numpy(), ref), (k, int((idx.numpy() != ref).any(axis=1).sum()))
+        diff = src[ref] - q[:, None, :]
+        assert np.array_equal(dist.numpy(), np.sqrt((diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]))
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"MM_KNN_LANE_T": "6", "MM_KNN_LANE_W": "1"},    # nearly every round is widened
+                                   {"MM_KNN_LANE_T": "6", "MM_KNN_LANE_W": "3"},
+                                   {"MM_KNN_LANE_T": "3", "MM_KNN_LANE_W": "2", "MM_KNN_LANE_Z": "12"},
+                                   {"MM_KNN_LANE_T": "1", "MM_KNN_LANE_W": "1"}])  # whole cell layers, as in round 2
+def test_knn_lane_kernel_windows_of_thin_layers_and_their_widening(knobs):
+    # the lane kernel first scans 2 W + 1 thin layers of the tile and, when a round cannot be certified, the
+    # entries a full cell layer adds on either side.  The knobs are read once per process, so every setting runs
+    # in a child process: forced to the lane kernel, narrow windows make the widening path the common one.
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MM_KNN_KERNEL="lane", **knobs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LANE_WINDOW_CHECK], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_knn_list_mode_one_wave_per_target(ctx, monkeypatch):
     # the kernel that serves the targets the fast kernels hand over (and the locate stage's lazily fetched full
