@@ -60,6 +60,7 @@ enum mm_buffer_slot {
     MM_BUF_L_NODES,                       //   allocates once
     MM_BUF_L_W,
     MM_BUF_L_PTS,
+    MM_BUF_LOC_SLOW,                      // locate stage: list of targets for the reference-order kernel + its counters
     MM_BUF_LEVELS,                        // density levels of the kNN grid: {cell_start, sorted_xyz} per level
     MM_BUF_COUNT = MM_BUF_LEVELS + 2 * 8
 };
@@ -122,8 +123,10 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
                           const double *fields, i64 nnodes, i64 ncomp, double *out,
                           const mm_lazy_lists *lazy, const double *tsorted = nullptr);
 // full-length int32 lists for a device-side list of targets (generic kernel, rows idx[i*k ...])
+// list_len_hint: the list's length when the caller has read it back (long lists then take the tiled kernels, which carve
+// the context's scratch pool anew), -1 when it is only known on the device
 int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,
-                           int *idx_d, const int *list, const int *list_count);
+                           int *idx_d, const int *list, const int *list_count, i64 list_len_hint);
 int mm_launch_gather(mm_context *ctx, const double *fields, i64 nsrc, i64 ncomp, const i64 *ids,
                      const double *w, i64 npoints, i64 P, double *out, int out_point_major);
 

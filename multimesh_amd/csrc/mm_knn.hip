@@ -54,6 +54,7 @@ constexpr double kSparseShare = 0.25;
 constexpr i64 kLevelMinSources = 4096;
 constexpr i64 kLevelMaxCells = (i64)1 << 27;
 constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a denser level above this home-cell count
+constexpr i64 kLongListMin = 32768;  // on-demand list queries at least this long go through the tiled cascade (mm_knn_query_list_impl)
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
@@ -2897,8 +2898,11 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
 // rows were written in that order, null when they are in the targets' own order (paths without the lane kernel).
 template <typename IDX>
 static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, IDX *idx_d,
-                           double *dist_d, const double **tsorted_out)
+                           double *dist_d, const double **tsorted_out, const int *list0 = nullptr,
+                           const int *list0_count = nullptr)
 {
+    // list0 (device): only the targets list0[0 .. *list0_count) are served (rows by the targets' own indices as ever);
+    // the tiled kernels then walk just the strips that hold any of them (k <= 32)
     if (tsorted_out) *tsorted_out = nullptr;
     if (npts == 0 || k == 0) return MM_OK;
     MM_REQUIRE(npts < (i64)0x7fffffff, "too many targets for one query");
@@ -2943,7 +2947,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         const int nt = (int)((nc + kScanTile - 1) / kScanTile);
         need += mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
                 (l->fine ? mm_round256((size_t)npts * sizeof(int)) : 0) +   // targets passed down
-                (l != ix ? mm_round256((size_t)npts * sizeof(unsigned)) : 0) +   // strips that hold targets
+                ((l != ix || list0) ? mm_round256((size_t)npts * sizeof(unsigned)) : 0) +   // strips that hold targets
                 mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
                 2 * mm_round256((size_t)(nc + 1) * sizeof(int)) +       // counts, start
                 mm_round256((size_t)nt * sizeof(int)) + 256;
@@ -2965,7 +2969,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     // (MM_KNN_FORCE_LIST here and MM_KNN_LEVELS / MM_KNN_PER_CELL in the build are read per call on purpose: tests switch them
     // inside one process; every other knob is read once)
     const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;
-    if (force_list) use_lane = false;
+    if (force_list || list0) use_lane = false;
     static const bool unsorted_rows = getenv("MM_KNN_UNSORTED_ROWS") != nullptr;
     const bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !unsorted_rows;
     lane_work.sorted_rows = sorted_rows ? 1 : 0;
@@ -3007,7 +3011,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     }
     MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 256 * (size_t)(1 + nlevels), ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
-    const int *list = nullptr, *list_count = nullptr;   // level 0: every target
+    const int *list = list0, *list_count = list0_count;   // level 0: every target (or the caller's list)
     int level = 0;
     if (force_list)
         hipLaunchKernelGGL(list_all_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, fb_list, fb_count, npts);
@@ -3022,7 +3026,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
         int *down_count = fb_count + 64 * (1 + level);
         int *strip_count = down_count + 1;
-        unsigned *strip_list = level > 0 ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
+        unsigned *strip_list = (level > 0 || list0) ? (unsigned *)mm_scratch_take(ctx, (size_t)npts * sizeof(unsigned)) : nullptr;
         double *tsorted = nullptr;
         if (sorted_rows) {
             // (outlives this call's scratch: the locate stage reads it)
@@ -3033,7 +3037,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
         }
         if (!tsorted || !cell_of || !counts || !start || !tile_sums || !down_count || (l->fine && !down_list) ||
-            (level > 0 && !strip_list)) {
+            ((level > 0 || list0) && !strip_list)) {
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
@@ -3096,10 +3100,16 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
 }
 
 int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,
-                           int *idx_d, const int *list, const int *list_count)
+                           int *idx_d, const int *list, const int *list_count, i64 list_len_hint)
 {
     if (npts == 0 || k == 0) return MM_OK;
     const int kout = (int)k;
+    // list_len_hint >= 0: the caller has read the list's length back.  A LONG list (graded meshes: a tenth of the targets
+    // exhaust their eight lazily evaluated candidates) goes through the tiled kernels level by level, restricted to the
+    // strips that hold listed targets -- the list-mode kernels below serve one target per lane or per wave, which is
+    // right for the stragglers of a uniform mesh and 5-10x too slow for a million targets.  (The caller must not keep
+    // anything in the context's scratch pool across this call: the cascade carves it anew.)
+    if (list_len_hint >= kLongListMin && k <= 32) return knn_query_typed<int>(ctx, ix, pts_d, npts, k, idx_d, nullptr, nullptr, list, list_count);
     LevelTable lv;
     lv.n = 0;
     for (const mm_knn_index *l = ix; l && lv.n < kMaxLevels; l = l->fine) {

@@ -701,7 +701,7 @@ int launch_locate(mm_context *ctx, i64 k, int kavail, i64 npoints, const IDX *nn
         if (grid < 256) grid = full_grid < 256 ? full_grid : 256;
         if (lazy && !full && jdone >= kavail) {
             hipLaunchKernelGGL(gll_queue_ids_kernel, dim3(64), dim3(256), 0, ctx->stream, q_in, counters + c, id_list);
-            int rc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, k, lazy->nn_full, id_list, counters + c);
+            int rc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, k, lazy->nn_full, id_list, counters + c, -1);
             if (rc != MM_OK) return rc;
             full = true;
         }

@@ -667,14 +667,12 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
 
-    int rc = mm_scratch_begin(ctx, mm_round256((size_t)npoints * sizeof(int)) + 4096);
+    // (a buffer of its own, not the scratch pool: a long list's on-demand neighbour query carves the pool anew)
+    char *slow_block = nullptr;
+    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, mm_round256((size_t)npoints * sizeof(int)) + 256, (void **)&slow_block);
     if (rc != MM_OK) return rc;
-    int *slow = (int *)mm_scratch_take(ctx, (size_t)npoints * sizeof(int));
-    int *counters = (int *)mm_scratch_take(ctx, 256);  // [15] length of the reference-order list
-    if (!slow || !counters) {
-        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
-        return MM_ERR_ALLOC;
-    }
+    int *counters = (int *)slow_block;                 // [15] length of the reference-order list
+    int *slow = (int *)(slow_block + 256);
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
     i64 resident = 0;
@@ -726,8 +724,17 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         i64 k_slow = k;
         const IDX *nn_slow = nn;
         if (lazy && sizeof(IDX) == sizeof(int)) {
+            // A graded cloud (the index has density levels) leaves long lists here -- elongated elements whose centroid
+            // is not among a target's eight nearest --: worth one small readback to send them through the tiled kernels
+            // instead of the list-mode ones.  A uniform mesh (no levels) leaves none or a handful: no readback.
+            i64 list_len = -1;
+            if (lazy->index->fine) {
+                MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 1, slow_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                list_len = (i64) * reinterpret_cast<const int *>(ctx->h_counters + 1);
+            }
             int lrc = mm_knn_query_list_impl(ctx, lazy->index, pts, npoints, lazy->k_full, lazy->nn_full, slow,
-                                             slow_count);
+                                             slow_count, list_len);
             if (lrc != MM_OK) return lrc;
             k_slow = lazy->k_full;
             nn_slow = reinterpret_cast<const IDX *>(lazy->nn_full);
