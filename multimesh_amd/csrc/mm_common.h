@@ -123,6 +123,9 @@ int mm_launch_locate_hex8(mm_context *ctx, i64 k, i64 npoints, const void *nn, b
                           const double *fields, i64 nnodes, i64 ncomp, double *out,
                           const mm_lazy_lists *lazy, const double *tsorted = nullptr);
 // full-length int32 lists for a device-side list of targets (generic kernel, rows idx[i*k ...])
+// on-demand list queries at least this long (graded meshes) take the tiled kernels; the locate stage then also walks
+// the rest of those targets' candidates with its pass kernel before the reference-order kernel sees what is left
+#define MM_LONG_LIST_MIN 32768
 // list_len_hint: the list's length when the caller has read it back (long lists then take the tiled kernels, which carve
 // the context's scratch pool anew), -1 when it is only known on the device
 int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k,

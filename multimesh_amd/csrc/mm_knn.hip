@@ -54,7 +54,7 @@ constexpr double kSparseShare = 0.25;
 constexpr i64 kLevelMinSources = 4096;
 constexpr i64 kLevelMaxCells = (i64)1 << 27;
 constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a denser level above this home-cell count
-constexpr i64 kLongListMin = 32768;  // on-demand list queries at least this long go through the tiled cascade (mm_knn_query_list_impl)
+constexpr i64 kLongListMin = MM_LONG_LIST_MIN;  // on-demand list queries at least this long go through the tiled cascade (mm_knn_query_list_impl)
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
 constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
@@ -2719,13 +2719,17 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     ix->ncells = ncells;
     const GridParams g = params_of(ix);
 
+    // sorted_xyz holds nsrc + 1 records: the tile staging of the strip and cell kernels lets the lane of an
+    // EMPTY cell load "its first record" with the others (the value is discarded), and for the empty cells
+    // behind the last source that is record nsrc -- past the end of an array of nsrc records, and past the
+    // end of its mapping when nsrc * 32 bytes is a whole number of pages (a memory fault that came and went
+    // with what the allocator had mapped behind it)
     hipError_t e = hipSuccess;
     if (use_context_buffers) {
         ix->borrowed = true;
         int brc = mm_buffer_get(ctx, slot_cells, (size_t)(ncells + 1) * sizeof(int), (void **)&ix->cell_start);
         if (brc == MM_OK)
-            brc = mm_buffer_get(ctx, slot_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double),
-                                (void **)&ix->sorted_xyz);
+            brc = mm_buffer_get(ctx, slot_xyz, (size_t)(nsrc + 1) * kRec * sizeof(double), (void **)&ix->sorted_xyz);
         if (brc != MM_OK) {
             free_index(ix);
             return brc;
@@ -2733,7 +2737,7 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     } else {
         e = hipMalloc((void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
         if (e == hipSuccess)
-            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc > 0 ? nsrc : 1) * kRec * sizeof(double));
+            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc + 1) * kRec * sizeof(double));
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_ALLOC, "kNN index allocation failed: %s", hipGetErrorString(e));
             free_index(ix);

@@ -409,8 +409,14 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                                                                  const double *__restrict__ nodes,
                                                                  const double *__restrict__ pts,
                                                                  int *__restrict__ slow_list,
-                                                                 int *__restrict__ slow_count)
+                                                                 int *__restrict__ slow_count,
+                                                                 const int *__restrict__ in_list,
+                                                                 const int *__restrict__ in_count, int j0)
 {
+    // in_list (nullable, not with SORTED): only the targets in_list[0 .. *in_count), each from candidate j0 on -- the second
+    // pass over the targets that exhausted their lazily evaluated candidates, on their full lists (nn then holds k = the
+    // full length per row; candidates before j0 were rejected by the first pass and would be rejected again).
+    if (in_list) npoints = (i64)*in_count;
     // [wave][tier][entry]: tier 0 ordinary retries, 1 solves that outlasted kPassIters, 2 ... kMidIters
     __shared__ int2 s_queue0[kPassBlock / 64][kWaveQueue0];
     __shared__ int2 s_queue12[kPassBlock / 64][2][kWaveQueue];
@@ -475,7 +481,8 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
         } else if (next < total) {
             const i64 q = next + lane;
             active = q < total;
-            if (active) i = q;
+            if (active) i = in_list ? (i64)in_list[q] : q;
+            j = j0;
             next += nwaves * 64;
         } else if (held0 > 0) {
             // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
@@ -669,10 +676,11 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
 
     // (a buffer of its own, not the scratch pool: a long list's on-demand neighbour query carves the pool anew)
     char *slow_block = nullptr;
-    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, mm_round256((size_t)npoints * sizeof(int)) + 256, (void **)&slow_block);
+    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, 2 * mm_round256((size_t)npoints * sizeof(int)) + 256, (void **)&slow_block);
     if (rc != MM_OK) return rc;
-    int *counters = (int *)slow_block;                 // [15] length of the reference-order list
+    int *counters = (int *)slow_block;                 // [15] length of the reference-order list, [14] of the second pass's
     int *slow = (int *)(slow_block + 256);
+    int *slow2 = (int *)(slow_block + 256 + mm_round256((size_t)npoints * sizeof(int)));
     MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
     int *slow_count = counters + 15;
     i64 resident = 0;
@@ -700,7 +708,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         const bool nid32 = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
 #define MM_PASS_LAUNCH(EX, SO, NID, P)                                                                                  \
     hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, SO, NID>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, \
-                       nodes, P, slow, slow_count)
+                       nodes, P, slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0)
         if (tsorted && conn_is_exodus) {
             if (nid32) MM_PASS_LAUNCH(true, true, int, tsorted);
             else MM_PASS_LAUNCH(true, true, i64, tsorted);
@@ -738,6 +746,29 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
             if (lrc != MM_OK) return lrc;
             k_slow = lazy->k_full;
             nn_slow = reinterpret_cast<const IDX *>(lazy->nn_full);
+            if (list_len >= MM_LONG_LIST_MIN) {
+                // a long list: its targets walk the REST of their candidates (from the k-th on) in a second launch of
+                // the pass kernel; only what finds no acceptance there either is left to the reference-order kernel
+                // (which starts again at candidate 0: smallest-error fallback, failures)
+                int *slow2_count = counters + 14;
+                i64 g2 = (list_len + kPassBlock - 1) / kPassBlock;
+                if (g2 > resident) g2 = resident;
+                dim3 g_((unsigned)g2), b_(block);
+                const bool nid32b = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
+#define MM_PASS2_LAUNCH(EX, NID)                                                                                          \
+    hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, false, NID>), g_, b_, 0, ctx->stream, k_slow, npoints, nn_slow, conn,   \
+                       nelem, em, nodes, pts, slow2, slow2_count, (const int *)slow, (const int *)slow_count, (int)k)
+                if (conn_is_exodus) {
+                    if (nid32b) MM_PASS2_LAUNCH(true, int);
+                    else MM_PASS2_LAUNCH(true, i64);
+                } else {
+                    if (nid32b) MM_PASS2_LAUNCH(false, int);
+                    else MM_PASS2_LAUNCH(false, i64);
+                }
+#undef MM_PASS2_LAUNCH
+                slow = slow2;
+                slow_count = slow2_count;
+            }
         }
         i64 sgrid = full_grid >> 3;
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;

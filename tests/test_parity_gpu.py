@@ -459,6 +459,27 @@ def test_graded_meshes_through_the_pipeline(ctx):
         assert np.array_equal(vals.numpy(), vals_o) and np.array_equal(v2.numpy(), vals_o)
 
 
+def test_graded_mesh_with_a_long_list_of_exhausted_targets(ctx):
+    # a graded mesh on which well over 32768 targets find no acceptance among their 8 lazily evaluated candidates
+    # (elongated elements: the containing element's centroid is not among the nearest): their full lists come from
+    # the tiled kNN kernels restricted to the list, a second launch of the locate pass kernel walks candidates
+    # 8 .. 19, and only what is left goes through the reference-order kernel.  Bit for bit against the oracle.
+    pa, ca = synth.hex_mesh(90, seed=3, jitter=0.1)
+    pb, _ = synth.hex_mesh(90, seed=9, jitter=0.1)
+    pa, pb = pa ** 2.2, pb ** 2.2
+    fields = synth.vector_field(pa)[:1]
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    conn = synth.reorder_hex8(ca)
+    enc_o, w_o, nf_o, status = O.locate_hex8(nn, conn, pa, pb, want_status=True)
+    assert (status >= 8).sum() + (status < 0).sum() > 40_000          # accepted beyond the 8th candidate, fallback or failed
+    vals_o = O.gather(fields, enc_o, w_o)
+    vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+    assert nf == nf_o
+    assert np.array_equal(enc.numpy(), enc_o) and np.array_equal(w.numpy(), w_o) and np.array_equal(vals.numpy(), vals_o)
+    v2, nf2 = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+    assert nf2 == nf_o and np.array_equal(v2.numpy(), vals_o)
+
+
 # ------------------------------------------------------------------------------- A10 GLL (parity unpinned)
 @pytest.mark.parametrize("order,dim", [(o, d) for o in (1, 2, 4) for d in (2, 3)])
 def test_gll_locate_and_gather_equal_the_oracle(ctx, order, dim):

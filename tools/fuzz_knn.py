@@ -12,6 +12,7 @@ from multimesh_amd.device import Context
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+start = int(sys.argv[4]) if len(sys.argv) > 4 else 0     # skip the cases before this one (same random sequence)
 ctx = Context(0)
 t0 = time.time()
 for case in range(ncases):
@@ -43,7 +44,7 @@ for case in range(ncases):
     k = int(rng.choice([1, 2, 3, 4, 7, 8, 13, 16, 20, 24, 25, 31, 32, 33, 40, 64]))
     k = min(k, nsrc)
     want_dist = bool(rng.random() < 0.5)
-    if only >= 0 and case != only:
+    if (only >= 0 and case != only) or case < start:
         continue
     tree = ctx.knn_build(src)
     res = tree.query(tgt, k, want_dist=True) if want_dist else (tree.query(tgt, k), None)
