@@ -35,7 +35,17 @@ struct mm_scratch {
     char *base = nullptr;
     size_t capacity = 0;
     size_t used = 0;
+    void *guard_piece[64] = {};   // MM_GUARD_ALLOC runs: every carve is an allocation of its own
+    int guard_pieces = 0;
 };
+
+// Device allocations of the library go through these two.  With MM_GUARD_ALLOC=1 in the environment (test
+// runs: tools/guard_run.sh) every allocation -- and every scratch carve -- is mapped so that it ENDS at the
+// end of its mapping with unmapped address space behind it: a kernel that reads or writes past an array
+// faults at once instead of now and then (there is no GPU AddressSanitizer on this pool).
+hipError_t mm_raw_alloc(int device, void **out, size_t bytes);
+hipError_t mm_raw_free(void *ptr);
+bool mm_guard_alloc(void);
 
 // Grow-only device buffers the fused pipeline reuses from call to call (hipMalloc/hipFree of
 // gigabyte-sized intermediates would otherwise cost milliseconds and a device sync per call).
@@ -91,6 +101,9 @@ struct mm_context {
 int mm_scratch_begin(mm_context *ctx, size_t total);
 void *mm_scratch_take(mm_context *ctx, size_t bytes);
 static inline size_t mm_round256(size_t b) { return (b + 255) & ~(size_t)255; }
+// bytes to clear for a carve of `b` bytes: whole 256-byte units (the carve is rounded up to them, and an odd
+// tail costs a second fill dispatch) -- except under MM_GUARD_ALLOC, where the carve ends with its array
+static inline size_t mm_fill_span(size_t b) { return mm_guard_alloc() ? b : mm_round256(b); }
 
 // Cached buffer of at least `bytes` for `slot` (grows by reallocation, after a stream sync).
 int mm_buffer_get(mm_context *ctx, int slot, size_t bytes, void **out);

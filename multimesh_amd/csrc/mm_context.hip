@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "mm_common.h"
 
@@ -21,6 +23,99 @@ void mm_set_error(int code, const char *fmt, ...)
 extern "C" const char *mm_last_error(void) { return g_err; }
 extern "C" int mm_last_status(void) { return g_status; }
 void mm_clear_status(void) { g_status = MM_OK; }
+
+// ---- allocation (with the guarded variant of test runs) ------------------------------------------------
+namespace {
+struct GuardBlock {
+    void *user, *va;
+    size_t reserved, mapped;
+    hipMemGenericAllocationHandle_t handle;
+};
+std::mutex g_guard_mutex;
+std::vector<GuardBlock> g_guard_blocks;
+}  // namespace
+
+bool mm_guard_alloc(void)
+{
+    static const bool on = getenv("MM_GUARD_ALLOC") != nullptr && atoi(getenv("MM_GUARD_ALLOC")) != 0;
+    return on;
+}
+
+hipError_t mm_raw_alloc(int device, void **out, size_t bytes)
+{
+    if (!mm_guard_alloc()) return hipMalloc(out, bytes);
+    *out = nullptr;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = (size_t)2 << 20;
+    // the array ends at the end of the mapping (16-byte granules: vector loads stay aligned); one granule
+    // of reserved, unmapped addresses follows it
+    GuardBlock b = {};
+    const size_t user = (bytes + 15) & ~(size_t)15;
+    b.mapped = (user + gran - 1) / gran * gran;
+    b.reserved = b.mapped + gran;
+    e = hipMemAddressReserve(&b.va, b.reserved, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&b.handle, b.mapped, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(b.va, b.reserved); return e; }
+    e = hipMemMap(b.va, b.mapped, 0, b.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(b.va, b.mapped, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(b.va, b.mapped);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemRelease(b.handle);
+        (void)hipMemAddressFree(b.va, b.reserved);
+        return e;
+    }
+    b.user = (char *)b.va + (b.mapped - user);
+    {
+        std::lock_guard<std::mutex> lock(g_guard_mutex);
+        g_guard_blocks.push_back(b);
+    }
+    *out = b.user;
+    return hipSuccess;
+}
+
+hipError_t mm_raw_free(void *ptr)
+{
+    if (!ptr) return hipSuccess;
+    if (!mm_guard_alloc()) return hipFree(ptr);
+    GuardBlock b = {};
+    {
+        std::lock_guard<std::mutex> lock(g_guard_mutex);
+        size_t at = 0;
+        while (at < g_guard_blocks.size() && g_guard_blocks[at].user != ptr) ++at;
+        if (at == g_guard_blocks.size()) return hipErrorInvalidValue;
+        b = g_guard_blocks[at];
+        g_guard_blocks.erase(g_guard_blocks.begin() + (long)at);
+    }
+    // The address range is NOT given back: a later reservation would get the same addresses, and kernels were
+    // seen to read through the stale translations of the previous mapping (zeros, or a fault at the old guard
+    // page).  A test process spends a few hundred GB of its 128 TB of addresses instead; the memory itself is
+    // released.
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemUnmap(b.va, b.mapped);
+    if (e == hipSuccess) e = hipMemRelease(b.handle);
+    return e;
+}
+
+static void scratch_release(mm_context *ctx)
+{
+    for (int q = 0; q < ctx->scratch.guard_pieces; ++q) (void)mm_raw_free(ctx->scratch.guard_piece[q]);
+    ctx->scratch.guard_pieces = 0;
+    if (ctx->scratch.base) (void)mm_raw_free(ctx->scratch.base);
+    ctx->scratch.base = nullptr;
+    ctx->scratch.capacity = 0;
+}
 
 extern "C" int mm_device_count(void)
 {
@@ -48,12 +143,12 @@ extern "C" int mm_context_create(int device, void *hip_stream, mm_context **out)
     }
     ctx->device = device;
     ctx->stream = (hipStream_t)hip_stream;
-    hipError_t e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(i64));
+    hipError_t e = mm_raw_alloc(device, (void **)&ctx->d_counters, 64 * sizeof(i64));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(i64), 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_misc, hipEventDisableTiming);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
-        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_counters) (void)mm_raw_free(ctx->d_counters);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         delete ctx;
         return MM_ERR_HIP;
@@ -68,10 +163,10 @@ extern "C" void mm_context_destroy(mm_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+    scratch_release(ctx);
     for (int s = 0; s < MM_BUF_COUNT; ++s)
-        if (ctx->buf_ptr[s]) (void)hipFree(ctx->buf_ptr[s]);
-    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->buf_ptr[s]) (void)mm_raw_free(ctx->buf_ptr[s]);
+    if (ctx->d_counters) (void)mm_raw_free(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev_misc) (void)hipEventDestroy(ctx->ev_misc);
     for (int q = 0; q < 3; ++q)
@@ -99,7 +194,7 @@ extern "C" int mm_device_alloc(mm_context *ctx, size_t bytes, void **dptr)
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     *dptr = nullptr;
     if (bytes == 0) bytes = 256;
-    hipError_t e = hipMalloc(dptr, bytes);
+    hipError_t e = mm_raw_alloc(ctx->device, dptr, bytes);
     if (e != hipSuccess) {
         mm_set_error(MM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return MM_ERR_ALLOC;
@@ -113,7 +208,7 @@ extern "C" int mm_device_free(mm_context *ctx, void *dptr)
     if (!dptr) return MM_OK;
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    MM_HIP_CHECK(hipFree(dptr));
+    MM_HIP_CHECK(mm_raw_free(dptr));
     return MM_OK;
 }
 
@@ -153,6 +248,14 @@ extern "C" int mm_memset(mm_context *ctx, void *dst_d, int value, size_t bytes)
 int mm_scratch_begin(mm_context *ctx, size_t total)
 {
     total = mm_round256(total) + 4096;
+    if (mm_guard_alloc()) {
+        // every carve is an allocation of its own, given back when the next call begins
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        scratch_release(ctx);
+        ctx->scratch.capacity = total;   // (the carves are still checked against the reservation)
+        ctx->scratch.used = 0;
+        return MM_OK;
+    }
     if (total > ctx->scratch.capacity) {
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch.base) MM_HIP_CHECK(hipFree(ctx->scratch.base));
@@ -173,6 +276,15 @@ int mm_scratch_begin(mm_context *ctx, size_t total)
 
 void *mm_scratch_take(mm_context *ctx, size_t bytes)
 {
+    if (mm_guard_alloc()) {
+        if (ctx->scratch.used + mm_round256(bytes) > ctx->scratch.capacity) return nullptr;
+        if (ctx->scratch.guard_pieces >= 64) return nullptr;
+        void *p = nullptr;
+        if (mm_raw_alloc(ctx->device, &p, bytes > 0 ? bytes : 16) != hipSuccess) return nullptr;
+        ctx->scratch.guard_piece[ctx->scratch.guard_pieces++] = p;
+        ctx->scratch.used += mm_round256(bytes);
+        return p;
+    }
     bytes = mm_round256(bytes);
     if (ctx->scratch.used + bytes > ctx->scratch.capacity) return nullptr;
     void *p = ctx->scratch.base + ctx->scratch.used;
@@ -183,13 +295,14 @@ void *mm_scratch_take(mm_context *ctx, size_t bytes)
 int mm_buffer_get(mm_context *ctx, int slot, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 256;
-    if (bytes > ctx->buf_cap[slot]) {
+    // (guarded runs: exactly the size asked for, so that the array ends with its mapping)
+    if (bytes > ctx->buf_cap[slot] || (mm_guard_alloc() && bytes != ctx->buf_cap[slot])) {
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->buf_ptr[slot]) MM_HIP_CHECK(hipFree(ctx->buf_ptr[slot]));
+        if (ctx->buf_ptr[slot]) MM_HIP_CHECK(mm_raw_free(ctx->buf_ptr[slot]));
         ctx->buf_ptr[slot] = nullptr;
         ctx->buf_cap[slot] = 0;
-        const size_t want = mm_round256(bytes + bytes / 16);
-        hipError_t e = hipMalloc(&ctx->buf_ptr[slot], want);
+        const size_t want = mm_guard_alloc() ? bytes : mm_round256(bytes + bytes / 16);
+        hipError_t e = mm_raw_alloc(ctx->device, &ctx->buf_ptr[slot], want);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_ALLOC, "hipMalloc(%zu) for pipeline buffer %d failed: %s", want, slot,
                          hipGetErrorString(e));

@@ -2651,8 +2651,8 @@ void free_index(mm_knn_index *ix)
     if (!ix) return;
     free_index(ix->fine);
     if (!ix->borrowed) {
-        if (ix->cell_start) (void)hipFree(ix->cell_start);
-        if (ix->sorted_xyz) (void)hipFree(ix->sorted_xyz);
+        if (ix->cell_start) (void)mm_raw_free(ix->cell_start);
+        if (ix->sorted_xyz) (void)mm_raw_free(ix->sorted_xyz);
     }
     delete ix;
 }
@@ -2735,9 +2735,9 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
             return brc;
         }
     } else {
-        e = hipMalloc((void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
+        e = mm_raw_alloc(ctx->device, (void **)&ix->cell_start, (size_t)(ncells + 1) * sizeof(int));
         if (e == hipSuccess)
-            e = hipMalloc((void **)&ix->sorted_xyz, (size_t)(nsrc + 1) * kRec * sizeof(double));
+            e = mm_raw_alloc(ctx->device, (void **)&ix->sorted_xyz, (size_t)(nsrc + 1) * kRec * sizeof(double));
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_ALLOC, "kNN index allocation failed: %s", hipGetErrorString(e));
             free_index(ix);
@@ -2759,7 +2759,7 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         return MM_ERR_ALLOC;
     }
     // (whole 256-byte units -- the carve is rounded up to them --: an odd tail costs a second fill dispatch)
-    e = hipMemsetAsync(counts, 0, mm_round256((size_t)(ncells + 1) * sizeof(int)), ctx->stream);
+    e = hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream);
     if (e != hipSuccess) { mm_set_error(MM_ERR_HIP, "memset: %s", hipGetErrorString(e)); free_index(ix); return MM_ERR_HIP; }
     const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
     if (nsrc > 0)
@@ -3045,7 +3045,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
-        MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_round256((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
+        MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
