@@ -147,26 +147,39 @@ def measured_traffic(kernel_stage):
         return None
 
 
-def valu_floor(stage, ms, scale=1.0):
+def valu_floor(stage, ms, scale=1.0, pattern="*_knn_counters.json", key=None, kernel=None, run_steps=None):
     """VALU-issue floor of a kernel: wave-instructions per launch by class (profiles/*_knn_counters.json:
     SQ_INSTS_VALU and its ADD/MUL/FMA_F32 sub-counters, collected on the metric workload) x the issue cost of
     each class at saturation (profiles/*_valu_issue.json from tools/valu_issue.hip: the fp32 add/mul/fmac class
     issues every ~2.4 cycles per SIMD, everything else -- min/max/med3, compares, three-operand and 64-bit
     forms -- every ~4.4), spread over the chip's 1024 SIMDs at the measured clock.  `scale` rescales the counts
-    when the launch is not the metric workload's (targets ratio).  None when the profiles are absent."""
-    fc, fi = _latest("*_knn_counters.json"), _latest("*_valu_issue.json")
-    if not (fc and fi and stage in COUNTER_KEY):
+    when the launch is not the metric workload's (targets ratio).  key: the counter profile's kernel entry, or a
+    list of them with run_steps = the steps the counter run made: the kernels' run totals / run_steps are summed (a
+    stage of several launches per step).  None when the profiles are absent."""
+    fc, fi = _latest(pattern), _latest("*_valu_issue.json")
+    key = key or COUNTER_KEY.get(stage)
+    if not (fc and fi and key):
         return None
     try:
-        c = json.load(open(fc)).get(COUNTER_KEY[stage], {})
+        prof = json.load(open(fc))
         issue = json.load(open(fi))
-        total = c["SQ_INSTS_VALU"] * scale
-        fast = sum(c.get(n, 0.0) for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")) * scale
-        have_mix = "SQ_INSTS_VALU_ADD_F32" in c
+        fast_names = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")
+        if isinstance(key, (list, tuple)):
+            ents = [prof[kk] for kk in key if kk in prof]
+            if not ents:
+                return None
+            total = sum(e["SQ_INSTS_VALU_run_total"] for e in ents) / run_steps * scale
+            fast = sum(e.get(n + "_run_total", 0.0) for e in ents for n in fast_names) / run_steps * scale
+            have_mix = all("SQ_INSTS_VALU_ADD_F32_run_total" in e for e in ents)
+        else:
+            c = prof.get(key, {})
+            total = c["SQ_INSTS_VALU"] * scale
+            fast = sum(c.get(n, 0.0) for n in fast_names) * scale
+            have_mix = "SQ_INSTS_VALU_ADD_F32" in c
         slow = total - fast
         cyc = fast * issue["fast_class_cycles"] + slow * issue["slow_class_cycles"]
         floor_ms = cyc / N_SIMD / (issue["clock_GHz"] * 1e9) * 1e3
-        return {"kernel": KERNEL_OF_STAGE[stage], "valu_wave_insts_per_launch": round(total),
+        return {"kernel": kernel or KERNEL_OF_STAGE[stage], "valu_wave_insts_per_launch": round(total),
                 "fast_class_insts": round(fast) if have_mix else None,
                 "issue_cycles": {"fast_class": issue["fast_class_cycles"], "slow_class": issue["slow_class_cycles"]},
                 "clock_GHz": issue["clock_GHz"], "floor_ms": round(floor_ms, 4), "ms": round(ms, 4),
@@ -900,6 +913,11 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
                                        f"per step over {D.backend}") if D.use else "single GPU"},
             "nmissing": missing,
             "roofline": roofline,
+            # vector-issue floor of the Newton passes (instruction counts of profiles/*_gll_counters.json, collected on the
+            # default cfg5 sizes with tools/knn_counters.sh; per launch, rescaled by this rank's share of the targets)
+            "roofline_valu": {"locate": valu_floor("locate", loc_ms, scale=n_local / max(n_unique, 1), pattern="*_gll_counters.json",
+                                                   key=["locate_gll_first_pass_kernel", "locate_gll_pass_kernel"], run_steps=3,
+                                                   kernel="locate_gll_first_pass_kernel<4, 3, int> + locate_gll_pass_kernel<4, 3, int>")},
             "stages": {"unique_points": {"ms": round(st["unique_ms"] / steps, 4),
                                          "note": "mm_unique_points over all element-nodal target points (replicated on every rank)"},
                        **{s: {"ms": round(v, 4)} for s, v in sm.items() if v > 0}},

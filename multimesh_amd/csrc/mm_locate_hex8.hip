@@ -395,6 +395,14 @@ __device__ unsigned long long g_loc_stamps[kLocStampSlots * 8];
 #define MM_LSTAMP(n) do { } while (0)
 #endif
 
+// Diagnostic builds only (make EXTRA=-DMM_LOCATE_COUNT, printed with MM_LOCATE_DEBUG=1): rounds, lanes and solves of
+// the pass kernel, in the first words of the counter block whose word 15 is slow_count.
+#ifdef MM_LOCATE_COUNT
+#define MM_LCOUNT(slot, pred) do { if (pred) atomicAdd(slow_count - 15 + (slot), 1); } while (0)
+#else
+#define MM_LCOUNT(slot, pred) do { } while (0)
+#endif
+
 // SORTED: the targets come as cell-sorted records {x, y, z, index} (the kNN stage's) and the candidate rows in
 // the same order: a wave's 64 targets are 8 neighbouring grid cells -- coordinates and rows stream, and the
 // lanes share their candidate elements' connectivity rows and nodes.  i is then the position in that order
@@ -518,6 +526,9 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             break;
         }
         const int cap = tier == 0 ? kPassIters : (tier == 1 ? kMidIters : kRefIters);
+        MM_LCOUNT(0, lane == 0);
+        MM_LCOUNT(1, active);
+        MM_LCOUNT(6, lane == 0 && tier > 0);
         wave_fence();  // the queue reads above happen before this round's appends
         // outcome of this lane's candidate: 0 rejected, 1 accepted, 2 too slow for this cap (next tier),
         // 3 no candidate left
@@ -565,6 +576,18 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                     const double my = 0.05 * (yhi - ylo) + 1e-7 * fmax(xhi - xlo, yhi - ylo);
                     // NaN corners or point: comparisons are false -> treated as "inside" (never skipped)
                     outside = px < xlo - mx || px > xhi + mx || py < ylo - my || py > yhi + my;
+#ifdef MM_EXP_ZBOX   // experiment only (NOT the reference's semantics: it never tests the z residual)
+                    {
+                        double zlo = c.z[0], zhi = c.z[0];
+#pragma unroll
+                        for (int n = 1; n < 8; ++n) {
+                            zlo = fmin(zlo, c.z[n]);
+                            zhi = fmax(zhi, c.z[n]);
+                        }
+                        const double mz = (0.01 * MM_EXP_ZBOX) * (zhi - zlo);
+                        outside = outside || pz < zlo - mz || pz > zhi + mz;
+                    }
+#endif
                 }
                 if (!outside) {
                     have = true;
@@ -576,6 +599,7 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             asm volatile("" ::"v"(c.x[0]), "v"(c.z[7]));
             MM_LSTAMP(2);   // candidate row, connectivity row, corner coordinates, box test
 #endif
+            MM_LCOUNT(2, have && j < k);
             if (j >= k) {
                 outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
             } else if (have) {
@@ -598,6 +622,8 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                 }
             }
         }
+        MM_LCOUNT(3, active && outcome == 1);
+        MM_LCOUNT(5, active && outcome == 2);
         MM_LSTAMP(4);   // weights
         // the first lane of a target's group (the whole group when nobody works ahead) whose outcome is
         // not a rejection decides; if all rejected, the group's first lane moves on behind the group
@@ -788,6 +814,10 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         MM_HIP_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         fprintf(stderr, "[mm_locate] %lld targets; reference-order list %d\n", (long long)npoints, h[15]);
+#ifdef MM_LOCATE_COUNT
+        fprintf(stderr, "[mm_locate] rounds %d (slow tiers %d), active lanes %d, solves %d, accepted %d, sent to the next tier %d\n",
+                h[0], h[6], h[1], h[2], h[3], h[5]);
+#endif
     }
     return MM_OK;
 }

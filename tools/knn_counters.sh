@@ -6,7 +6,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/counters; rm -rf $O; mkdir -p $O
 OUT=${1:-$O/knn_counters.json}
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+# MM_COUNTER_ARGS: another workload (e.g. "bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline" ->
+# profiles/*_gll_counters.json); MM_COUNTER_VALU_ONLY=1: only the instruction-count groups roofline_valu needs
+ARGS=${MM_COUNTER_ARGS:-"bench.py --steps 2 --warmup 1 --no-cpu-baseline"}
 i=0
 for group in \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -17,6 +19,7 @@ for group in \
   "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT" \
   "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
+  if [ -n "$MM_COUNTER_VALU_ONLY" ]; then case "$group" in SQ_WAVES*|SQ_INSTS_VALU_ADD*) ;; *) continue;; esac; fi
   rocprofv3 --kernel-trace --pmc $group --output-format csv -d $O/pass$i -o p -- python3 $ARGS > $O/pass$i.log 2>&1 \
     || echo "pass $i ($group) failed: see $O/pass$i.log"
 done

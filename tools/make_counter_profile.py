@@ -17,7 +17,8 @@ root, out = sys.argv[1], sys.argv[2]
 PATTERNS = {"knn_strip_kernel": "knn_strip_kernel", "knn_lane_kernel": "knn_lane_kernel",
             "locate_pass_kernel": "locate_pass_kernel", "centroid_bbox_kernel": "centroid_bbox",
             "gather8_kernel": "gather8_kernel", "cell_scatter_kernel": "cell_scatter", "target_scatter_kernel": "target_scatter",
-            "cell_count_kernel": "cell_count"}
+            "cell_count_kernel": "cell_count", "locate_gll_first_pass_kernel": "locate_gll_first_pass_kernel",
+            "locate_gll_pass_kernel": "locate_gll_pass_kernel"}
 
 
 def short(name):
@@ -48,6 +49,11 @@ for k, counters in sorted(sums.items()):
         vals = sorted(per.values(), reverse=True)
         top = [v for v in vals if v >= 0.5 * vals[0]] if vals[0] > 0 else vals
         e[c] = round(sum(top) / len(top), 1)
+        if c.startswith("SQ_INSTS_VALU") or c == "SQ_WAVES":
+            # ... and the sum over ALL dispatches of the run (kernels launched several times per step, with different
+            # sizes: bench.py divides by the steps the run made)
+            e[c + "_run_total"] = round(sum(vals), 1)
+            e["dispatches_in_run"] = len(vals)
     if dur[k]:
         d = sorted(dur[k], reverse=True)
         top = [v for v in d if v >= 0.5 * d[0]]

@@ -8,6 +8,8 @@
 #   a 2-rank strong-scaling rehearsal on the one GPU.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
+R=${1:-r03}   # round tag: the fresh counter profiles are put under profiles/ (of the box's copy) before the plain
+              # bench lines are made, so that their roofline_valu reads THIS build's instruction counts
 step() { echo "[refresh] $*"; }
 step kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
@@ -19,6 +21,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -
 python3 tools/make_traffic_profile.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null || exit 1
 step counters
 bash tools/knn_counters.sh $O/knn_counters.json > $O/counters.log 2>&1
+MM_COUNTER_ARGS="bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline" MM_COUNTER_VALU_ONLY=1 \
+  bash tools/knn_counters.sh $O/gll_counters.json > $O/gll_counters.log 2>&1
+[ -s $O/knn_counters.json ] && cp $O/knn_counters.json profiles/${R}_knn_counters.json
+[ -s $O/gll_counters.json ] && cp $O/gll_counters.json profiles/${R}_gll_counters.json
 step cfg5 kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -o p -- python3 bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_under_rocprof.json 2> $O/stats5.err && cp $O/stats5/p_kernel_stats.csv $O/gll_cfg5_kernel_stats.csv
 step plain bench lines
