@@ -113,6 +113,14 @@ void mm_stage_reset(mm_context *ctx);
 void mm_stage_begin(mm_context *ctx, int stage);
 void mm_stage_end(mm_context *ctx, int stage);
 
+// Slots of mm_context::d_counters (64 x i64, zeroed when the context is created) / its pinned mirror h_counters:
+//   0 failed / missing points of the call    1 mm_layers' counter    8..15 the hex8 locate stage's 16 counters
+//   32..47 the grid statistic                48..53 (h_counters) the sources' bounding box
+// ("The last workgroup of a launch finishes the reduction" was tried for the bounding box and the scans and
+// measured: on this multi-XCD part the device-scope fence every workgroup needs before it takes its ticket writes
+// its XCD's L2 back -- the centroid kernel went from 0.26 to 0.72 ms, a scan's first kernel from 5 to 80 us.)
+constexpr int kMmStatSlot = 32, kMmBoxSlot = 48;
+
 // ---- internal launchers (device pointers, no synchronisation) -------------------------
 int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,
                        const double *points, double *out);

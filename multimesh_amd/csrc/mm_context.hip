@@ -144,6 +144,7 @@ extern "C" int mm_context_create(int device, void *hip_stream, mm_context **out)
     ctx->device = device;
     ctx->stream = (hipStream_t)hip_stream;
     hipError_t e = mm_raw_alloc(device, (void **)&ctx->d_counters, 64 * sizeof(i64));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 64 * sizeof(i64));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(i64), 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_misc, hipEventDisableTiming);
     if (e != hipSuccess) {

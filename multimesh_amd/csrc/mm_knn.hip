@@ -57,9 +57,9 @@ constexpr int kListKeepMax = 24;   // list-mode queries: a target moves to a den
 constexpr i64 kLongListMin = MM_LONG_LIST_MIN;  // on-demand list queries at least this long go through the tiled cascade (mm_knn_query_list_impl)
 constexpr int kSplitTargets = 128;   // strips with many more targets than this are shared between waves
 constexpr int kMaxSplit = 64;
-constexpr int kStatSlot = 32;  // slot of mm_context::d_counters / h_counters used for the statistic
+constexpr int kStatSlot = kMmStatSlot;  // slot of mm_context::d_counters / h_counters used for the statistic
 static_assert(kMaxLevels <= 16, "the level statistic has 16 counter slots");
-constexpr int kBoxSlot = 48;   // six doubles of the pinned h_counters receive the sources' bounding box
+constexpr int kBoxSlot = kMmBoxSlot;   // six doubles of the pinned h_counters receive the sources' bounding box
 
 struct GridParams {
     int nx, ny, nz;
@@ -109,14 +109,17 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const double *__re
     }
 }
 
+// out: the context's PINNED mirror of its counters -- the host reads the box after a stream synchronisation, no copy
+// dispatch; stat16 (nullable): the 16 words of the grid statistic the build accumulates next, cleared on the way.
 __global__ __launch_bounds__(kBlock) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
-                                                             double *__restrict__ out)
+                                                             double *__restrict__ out, long long *__restrict__ stat16)
 {
     // one workgroup per component (grid 6): the threads stride over the per-block partials -- eight independent
     // loads in flight each for the fused pipeline's 2048 partials: ONE round trip (a single wave walking them took
     // 35 us of an otherwise idle GPU in mid-step) --, then a butterfly per wave and four values through LDS
     __shared__ double s_part[kBlock / 64];
     const int a = blockIdx.x;
+    if (stat16 && a == 0 && threadIdx.x < 16) stat16[threadIdx.x] = 0;
     const double init = a < 3 ? INFINITY : -INFINITY;
     double v[8];
 #pragma unroll
@@ -150,31 +153,6 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
     double t = (x - lo) * ih;
     t = fmin(fmax(t, 0.0), (double)(n - 1));  // NaN -> 0, outside -> clamped
     return (int)t;
-}
-
-// total[b] += the counts of the cells holding more than kLevelCount[b] sources (density levels).
-// total[kMaxLevels - 1] += the counts of the cells holding at most kSparseCount sources, from every
-// 2^sample_shift-th workgroup only (an estimate that steers a heuristic: nearly every wave of a uniform cloud has
-// such a cell, and 17 k atomics on one address are 0.1 ms).
-__global__ __launch_bounds__(kBlock) void level_share_kernel(const int *__restrict__ counts, i64 ncells,
-                                                             unsigned long long *__restrict__ total, int sample_shift)
-{
-    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const int v = c < ncells ? counts[c] : 0;
-    if ((blockIdx.x & ((1u << sample_shift) - 1u)) == 0) {
-        int w = v <= kSparseCount ? v : 0;
-        if (__any(w > 0)) {
-            for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
-            if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(total + (kMaxLevels - 1), (unsigned long long)w);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < kMaxLevels - 1; ++b) {
-        int w = v > kLevelCount[b] ? v : 0;
-        if (!__any(w > 0)) break;   // thresholds ascend
-        for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
-        if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(total + b, (unsigned long long)w);
-    }
 }
 
 // With `list` the items are the points list[0 .. *list_count) (a density level's share of the targets).
@@ -242,13 +220,48 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
     return base + incl - v;
 }
 
+// First kernel of the scan: per-tile sums.  With `level_total` it also accumulates the grid statistic of the build
+// from the counts it reads anyway (no kernel of its own):
+//   level_total[b] += the counts of the cells holding more than kLevelCount[b] sources (density levels);
+//   level_total[kMaxLevels - 1] += the counts of the cells holding at most kSparseCount sources, from every
+//   2^sample_shift-th run of 256 cells only (an estimate that steers a heuristic: nearly every wave of a uniform
+//   cloud has such a cell, and 17 k atomics on one address are 0.1 ms).
 __global__ __launch_bounds__(kBlock) void scan_tile_sums_kernel(const int *__restrict__ counts, i64 n,
-                                                                int *__restrict__ tile_sums)
+                                                                int *__restrict__ tile_sums,
+                                                                unsigned long long *__restrict__ level_total,
+                                                                int sample_shift)
 {
     const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    int v[kScanItems];
     int s = 0;
-    for (int i = 0; i < kScanItems; ++i)
-        if (base + i < n) s += counts[base + i];
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = base + i < n ? counts[base + i] : 0;
+        s += v[i];
+    }
+    if (level_total) {
+        // (a wave holds one run of 256 consecutive cells: kScanItems = 4 per lane)
+        static_assert(kScanItems * 64 == 256, "the sparse share is sampled per run of 256 cells");
+        const unsigned run = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        if ((run & ((1u << sample_shift) - 1u)) == 0) {
+            int w = 0;
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i) w += v[i] <= kSparseCount ? v[i] : 0;
+            if (__any(w > 0)) {
+                for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+                if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(level_total + (kMaxLevels - 1), (unsigned long long)w);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kMaxLevels - 1; ++b) {
+            int w = 0;
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i) w += v[i] > kLevelCount[b] ? v[i] : 0;
+            if (!__any(w > 0)) break;   // thresholds ascend
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+            if ((threadIdx.x & 63) == 0 && w > 0) atomicAdd(level_total + b, (unsigned long long)w);
+        }
+    }
     int total;
     (void)block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
@@ -2664,7 +2677,8 @@ void free_index(mm_knn_index *ix)
 int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums)
 {
     const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums,
+                       (unsigned long long *)nullptr, 0);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums, start);
     MM_HIP_CHECK(hipGetLastError());
@@ -2677,7 +2691,7 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
 // for it) and *level_extra = the number of denser levels the cloud asks for.
 static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
                        bool use_context_buffers, int level, int *level_extra, mm_knn_index **out,
-                       double *sparse_share = nullptr)
+                       double *sparse_share = nullptr, bool stat_dirty = true)
 {
     static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
     const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
@@ -2766,17 +2780,20 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            counts, (const int *)nullptr, (const int *)nullptr);
     const bool want_stat = level_extra != nullptr && nsrc >= kLevelMinSources && live > 0;
-    const int sample_shift = (ncells + kBlock - 1) / kBlock >= 1024 ? 4 : 0;   // (the sparse share: see level_share_kernel)
+    const int sample_shift = (ncells + kBlock - 1) / kBlock >= 1024 ? 4 : 0;   // (the sparse share: see scan_tile_sums_kernel)
     if (level_extra) *level_extra = 0;
+    // scan of the counts; its first kernel also accumulates the grid statistic, which is then copied to the host while
+    // the rest of the scan and the scatter are still queued
+    i64 *stat = ctx->d_counters + kStatSlot;
+    // (slots kStatSlot .. +15 are the statistic's; bbox_final_kernel has cleared them for the
+    // first grid of a build, a coarsened second one clears them here)
+    if (want_stat && stat_dirty) e = hipMemsetAsync(stat, 0, 16 * sizeof(i64), ctx->stream);
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
+                           want_stat ? (unsigned long long *)stat : (unsigned long long *)nullptr, sample_shift);
     if (want_stat) {
-        i64 *stat = ctx->d_counters + kStatSlot;
-        e = hipMemsetAsync(stat, 0, 16 * sizeof(i64), ctx->stream);   // (slots kStatSlot .. +15 are the statistic's)
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(level_share_kernel, dim3((unsigned)((ncells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                               ctx->stream, counts, ncells, (unsigned long long *)stat, sample_shift);
-            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, kMaxLevels * sizeof(i64), hipMemcpyDeviceToHost,
-                               ctx->stream);
-        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, kMaxLevels * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
@@ -2784,7 +2801,6 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
             return MM_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                        ix->cell_start);
@@ -2830,25 +2846,29 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
                       bool use_context_buffers, const double *box_partial_d, int box_nblocks)
 {
     *out = nullptr;
-    // bounding box (one small synchronising readback; the build is a once-per-mesh step)
+    // bounding box: per-workgroup boxes -- left by the fused pipeline's centroid kernel (box_partial_d), or by
+    // bbox_partial_kernel here -- reduced by bbox_final_kernel straight into the context's PINNED mirror, which the
+    // host reads after a stream synchronisation (no copy dispatch; the build's one mid-call wait besides the grid
+    // statistic: the grid's dimensions size every launch that follows).  The same kernel clears the statistic.
     double box[6] = {0, 0, 0, 0, 0, 0};
     if (nsrc > 0) {
-        const int nblocks = (int)((nsrc + kBlock - 1) / kBlock < 1024 ? (nsrc + kBlock - 1) / kBlock : 1024);
-        int rc = mm_scratch_begin(ctx, (size_t)nblocks * 6 * sizeof(double) + 6 * sizeof(double) + 1024);
-        if (rc != MM_OK) return rc;
-        double *partial = (double *)mm_scratch_take(ctx, (size_t)nblocks * 6 * sizeof(double));
-        double *d_box = (double *)mm_scratch_take(ctx, 6 * sizeof(double));
-        if (box_partial_d) {
-            // the producer of the sources (the fused pipeline's centroid kernel) already left partials
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, box_partial_d, box_nblocks, d_box);
-        } else {
-            hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc,
-                               (int)ndim, partial);
-            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, partial, nblocks, d_box);
-        }
-        // (into the context's pinned mirror: a pageable destination goes through the runtime's staging path)
         double *h_box = reinterpret_cast<double *>(ctx->h_counters + kBoxSlot);
-        hipError_t e = hipMemcpyAsync(h_box, d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream);
+        long long *stat16 = reinterpret_cast<long long *>(ctx->d_counters + kStatSlot);
+        if (box_partial_d) {
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, box_partial_d, box_nblocks, h_box, stat16);
+        } else {
+            const int nblocks = (int)((nsrc + kBlock - 1) / kBlock < 1024 ? (nsrc + kBlock - 1) / kBlock : 1024);
+            int rc = mm_scratch_begin(ctx, (size_t)nblocks * 6 * sizeof(double) + 1024);
+            if (rc != MM_OK) return rc;
+            double *partial = (double *)mm_scratch_take(ctx, (size_t)nblocks * 6 * sizeof(double));
+            if (!partial) {
+                mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+                return MM_ERR_ALLOC;
+            }
+            hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, src_d, nsrc, (int)ndim, partial);
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, partial, nblocks, h_box, stat16);
+        }
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_HIP, "bounding box: %s", hipGetErrorString(e));
@@ -2872,7 +2892,7 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     for (int scale = 1;; scale *= 2) {
         double sparse = 0.0;
         rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, 0, max_levels > 1 ? &extra : nullptr,
-                         &head, &sparse);
+                         &head, &sparse, /*stat_dirty=*/scale > 1 || nsrc == 0);
         if (rc != MM_OK) return rc;
         if (scale >= 4 || !(sparse > sparse_limit)) break;
         free_index(head);   // a large sparse region: cells of twice the volume
@@ -3001,7 +3021,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
     // (one block, zeroed by ONE fill: the stragglers' counter, then every level's {passed down, strips} counters)
     int *fb_count = (int *)mm_scratch_take(ctx, 256 * (size_t)(1 + nlevels));
-    if (!fb_list || !fb_count) {
+    // (level 0's cell counts right behind the counters: ONE fill clears both)
+    int *counts0 = (int *)mm_scratch_take(ctx, (size_t)(ix->ncells + 1) * sizeof(int));
+    if (!fb_list || !fb_count || !counts0) {
         mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
         return MM_ERR_ALLOC;
     }
@@ -3013,7 +3035,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             return MM_ERR_ALLOC;
         }
     }
-    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 256 * (size_t)(1 + nlevels), ctx->stream));
+    const bool one_fill = !force_list && (char *)counts0 == (char *)fb_count + 256 * (size_t)(1 + nlevels);   // (not so under MM_GUARD_ALLOC)
+    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 256 * (size_t)(1 + nlevels) + (one_fill ? mm_round256((size_t)(ix->ncells + 1) * sizeof(int)) : 0),
+                                ctx->stream));
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
     const int *list = list0, *list_count = list0_count;   // level 0: every target (or the caller's list)
     int level = 0;
@@ -3025,7 +3049,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
         int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
         int *down_list = l->fine ? (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int)) : nullptr;
-        int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
+        int *counts = level == 0 ? counts0 : (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
         int *down_count = fb_count + 64 * (1 + level);
@@ -3045,10 +3069,12 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
-        MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
+        if (!(level == 0 && one_fill))
+            MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
-        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums);
+        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
+                           (unsigned long long *)nullptr, 0);
         hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
         hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim,

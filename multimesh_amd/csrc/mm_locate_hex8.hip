@@ -694,7 +694,15 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                                int conn_is_exodus, const Emit &em, const double *nodes, const double *pts,
                                i64 *d_nfailed, int zero_failed, const mm_lazy_lists *lazy, const double *tsorted)
 {
-    MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
+    // the failed-point counter and the stage's own 16 counters ([15] length of the reference-order list, [14] of the
+    // second pass's) sit in one block of the context's counter array (mm_common.h): ONE fill clears both
+    int *counters = reinterpret_cast<int *>(ctx->d_counters + 8);
+    if (d_nfailed == ctx->d_counters) {
+        MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(i64), ctx->stream));
+    } else {
+        MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
+        MM_HIP_CHECK(hipMemsetAsync(counters, 0, 16 * sizeof(int), ctx->stream));
+    }
     if (npoints == 0 || k == 0) return MM_OK;
     MM_REQUIRE(npoints < (i64)0x7fffffff, "too many targets for one launch");
     const int block = 256;
@@ -702,12 +710,10 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
 
     // (a buffer of its own, not the scratch pool: a long list's on-demand neighbour query carves the pool anew)
     char *slow_block = nullptr;
-    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, 2 * mm_round256((size_t)npoints * sizeof(int)) + 256, (void **)&slow_block);
+    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, 2 * mm_round256((size_t)npoints * sizeof(int)), (void **)&slow_block);
     if (rc != MM_OK) return rc;
-    int *counters = (int *)slow_block;                 // [15] length of the reference-order list, [14] of the second pass's
-    int *slow = (int *)(slow_block + 256);
-    int *slow2 = (int *)(slow_block + 256 + mm_round256((size_t)npoints * sizeof(int)));
-    MM_HIP_CHECK(hipMemsetAsync(counters, 0, 256, ctx->stream));
+    int *slow = (int *)slow_block;
+    int *slow2 = (int *)(slow_block + mm_round256((size_t)npoints * sizeof(int)));
     int *slow_count = counters + 15;
     i64 resident = 0;
     {
