@@ -242,6 +242,8 @@ enum mm_stage {
     MM_STAGE_LOCATE_PASS0 = 6, /* the first locate pass alone (inside MM_STAGE_LOCATE) */
     MM_STAGE_COUNT = 7
 };
+/* on: 0 no stage timers; 1 all stages; 2 only MM_STAGE_KNN_CELL and MM_STAGE_LOCATE_PASS0 (the two dominant
+ * kernels: every timed stage costs the stream two events, ~5 us each between kernels) */
 int mm_set_profiling(mm_context *ctx, int on);
 int mm_last_timings(mm_context *ctx, double *ms, int n);
 

@@ -155,7 +155,8 @@ class Context:
 
     # ---- timers -------------------------------------------------------------------------
     def set_profiling(self, on=True):
-        check(self.lib.mm_set_profiling(self.handle, 1 if on else 0), "mm_set_profiling")
+        """Stage timers: False / True (all stages) / 2 (only the kNN tile kernel and the first locate pass)."""
+        check(self.lib.mm_set_profiling(self.handle, 2 if on == 2 and on is not True else (1 if on else 0)), "mm_set_profiling")
 
     def set_lazy_lists(self, on=True):
         """interpolate_hex8 asks the kNN stage for the 8 nearest first and for the full list only for
