@@ -851,3 +851,29 @@ def test_bad_arguments_are_refused_with_a_code_and_a_message(ctx):
     # still alive
     vals, nf = ctx.interpolate_hex8(pa, ca, pa[:10], pa[:, 0].copy(), nelem_to_search=20)
     assert nf == 0 and np.abs(vals.numpy()[:, 0] - pa[:10, 0]).max() < 1e-7    # Newton tolerance 1e-8 x element size
+
+
+@pytest.mark.gpu
+def test_stage_timers_levels(ctx):
+    # mm_set_profiling: 1 times every stage of a call, 2 only the two dominant kernels (what bench.py runs its timed
+    # steps with: a timed stage costs the stream two events), 0 nothing; the results do not depend on it
+    pa, ca = synth.hex_mesh(30, seed=1, jitter=0.2)
+    pb, _ = synth.hex_mesh(31, seed=7, jitter=0.2)
+    fields = synth.vector_field(pa)[:1]
+    got = {}
+    try:
+        for level in (True, 2, False):
+            ctx.set_profiling(level)
+            vals, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+            t = ctx.last_timings()
+            got[level] = vals.numpy()
+            timed = {s for s, v in t.items() if v > 0.0}
+            if level is True:
+                assert {"centroid", "knn_build", "knn_query", "locate", "locate_pass0"} <= timed
+            elif level == 2:
+                assert timed <= {"knn_cell", "locate_pass0"} and "locate_pass0" in timed
+            else:
+                assert not timed
+    finally:
+        ctx.set_profiling(False)
+    assert np.array_equal(got[True], got[2]) and np.array_equal(got[True], got[False])
