@@ -36,105 +36,12 @@
 #include <cstring>
 
 #include "mm_common.h"
+#include "mm_newton_hex8.h"
 
 namespace {
 
-// Forward map of one axis (trilinearinterpolator.c:199-212) with named partials; each partial is
-// the same rounded quantity the reference's single expression produces.
-__device__ __forceinline__ double map_axis(const double (&v)[8], double hr, double hs, double ht)
-{
-    const double e03 = hr * (-v[0] + v[3]);
-    const double e12 = hr * (-v[1] + v[2]);
-    const double e45 = hr * (-v[4] + v[5]);
-    const double e76 = hr * (v[6] - v[7]);
-    const double bottom_s = hs * (((-v[0] + v[1]) - e03) + e12);
-    const double top_s = hs * (((-v[4] + v[7]) - e45) + e76);
-    const double along_t = ht * (((((-v[0] + v[4]) - e03) + e45) - bottom_s) + top_s);
-    return ((v[0] + e03) + bottom_s) + along_t;
-}
-
-// corner signs of trilinearinterpolator.c:8-10
-#define MM_R(n) ((n) == 2 || (n) == 3 || (n) == 5 || (n) == 6 ? 1.0 : -1.0)
-#define MM_S(n) ((n) == 1 || (n) == 2 || (n) == 6 || (n) == 7 ? 1.0 : -1.0)
-#define MM_T(n) ((n) >= 4 ? 1.0 : -1.0)
-
-// Newton inversion (trilinearinterpolator.c:260-305).  x/y/z hold the corner coordinates per
-// axis.  Returns true when converged; xi receives the last iterate either way.
-// first_it > 0 CONTINUES a solve: xi holds the iterate after first_it updates (the iteration is a deterministic map
-// of the iterate, so running trips [0, a) and later [a, b) gives the iterates of [0, b)); trips first_it .. max_it - 1.
-__device__ __forceinline__ bool newton_hex8(const double px, const double py, const double pz,
-                                            const double (&x)[8], const double (&y)[8],
-                                            const double (&z)[8], double (&xi)[3], const int max_it = 50,
-                                            const int first_it = 0)
-{
-    if (first_it == 0) {
-        xi[0] = 0.;
-        xi[1] = 0.;
-        xi[2] = 0.;
-    }
-    const double sx = fabs(x[1] - x[0]);
-    const double sy = fabs(y[1] - y[0]);
-    const double sz = fabs(z[1] - z[0]);
-    const double sxy = sx > sy ? sx : sy;
-    const double scale = sz > sxy ? sz : sxy;
-    const double tol = 1e-8 * scale;
-    for (int it = first_it; it < max_it; ++it) {
-        const double hr = 0.5 * (xi[0] + 1.0);
-        const double hs = 0.5 * (xi[1] + 1.0);
-        const double ht = 0.5 * (xi[2] + 1.0);
-        const double r0 = px - map_axis(x, hr, hs, ht);
-        const double r1 = py - map_axis(y, hr, hs, ht);
-        const double r2 = pz - map_axis(z, hr, hs, ht);
-        if (fabs(r0) < tol && fabs(r1) < tol) return true;  // z is never tested (reference quirk)
-        // Jacobian m[q][j] = sum_n dN_n/dxi_q * corner_n[j], accumulated from 0 in node order
-        double m[3][3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            m[q][0] = 0.;
-            m[q][1] = 0.;
-            m[q][2] = 0.;
-        }
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const double fs = xi[1] * MM_S(n) + 1;
-            const double ft = xi[2] * MM_T(n) + 1;
-            const double fr = xi[0] * MM_R(n) + 1;
-            const double d0 = 0.125 * MM_R(n) * fs * ft;
-            const double d1 = 0.125 * MM_S(n) * fr * ft;
-            const double d2 = 0.125 * MM_T(n) * fr * fs;
-            m[0][0] = m[0][0] + d0 * x[n];
-            m[0][1] = m[0][1] + d0 * y[n];
-            m[0][2] = m[0][2] + d0 * z[n];
-            m[1][0] = m[1][0] + d1 * x[n];
-            m[1][1] = m[1][1] + d1 * y[n];
-            m[1][2] = m[1][2] + d1 * z[n];
-            m[2][0] = m[2][0] + d2 * x[n];
-            m[2][1] = m[2][1] + d2 * y[n];
-            m[2][2] = m[2][2] + d2 * z[n];
-        }
-        const double det = m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) -
-                           m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-                           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-        const double rdet = 1 / det;
-        const double i00 = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * rdet;
-        const double i01 = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * rdet;
-        const double i02 = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * rdet;
-        const double i10 = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * rdet;
-        const double i11 = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * rdet;
-        const double i12 = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * rdet;
-        const double i20 = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * rdet;
-        const double i21 = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * rdet;
-        const double i22 = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * rdet;
-        // update = (J^-1)^T * residual, each row summed from 0 (trilinearinterpolator.c:362-375)
-        const double u0 = ((0. + i00 * r0) + i10 * r1) + i20 * r2;
-        const double u1 = ((0. + i01 * r0) + i11 * r1) + i21 * r2;
-        const double u2 = ((0. + i02 * r0) + i12 * r1) + i22 * r2;
-        xi[0] = xi[0] + u0;
-        xi[1] = xi[1] + u1;
-        xi[2] = xi[2] + u2;
-    }
-    return false;
-}
+// map_axis, newton_hex8 and the corner signs MM_R / MM_S / MM_T: mm_newton_hex8.h (shared with the host-side test of
+// its arithmetic, tests/test_newton_host.py)
 
 // Eight weights as expanded polynomials (trilinearinterpolator.c:174-197); the sign rides on
 // the exact constant 0.125 and the terms are added strictly left to right.

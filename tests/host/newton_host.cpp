@@ -1,0 +1,71 @@
+// Host build of multimesh_amd/csrc/mm_newton_hex8.h for tests/test_newton_host.py (test infrastructure; the product
+// compiles the same header as device code).  g++ -O2 -mfma -ffp-contract=off: the only fused operations are the
+// __builtin_fma calls the header spells out.
+#include <cstdint>
+#include <cstring>
+
+#include "../../multimesh_amd/csrc/mm_newton_hex8.h"
+
+extern "C" {
+
+// one solve, corners as the reference passes them (vtx[8][3]); trips first_it .. max_it - 1
+int nh_newton(const double *pnt, const double *vtx, double *xi, int max_it, int first_it)
+{
+    double x[8], y[8], z[8];
+    for (int n = 0; n < 8; ++n) {
+        x[n] = vtx[n * 3 + 0];
+        y[n] = vtx[n * 3 + 1];
+        z[n] = vtx[n * 3 + 2];
+    }
+    double q[3] = {xi[0], xi[1], xi[2]};
+    const bool ok = newton_hex8(pnt[0], pnt[1], pnt[2], x, y, z, q, max_it, first_it);
+    xi[0] = q[0];
+    xi[1] = q[1];
+    xi[2] = q[2];
+    return ok ? 1 : 0;
+}
+
+// other(pnt, vtx, xi, iters) -> converged: the oracle's mmo_hex8_newton (iters may be null), or with no_iters != 0
+// the compiled reference's inverseCoordinateTransform(pnt, vtx, xi).
+typedef int (*other4_t)(const double *, const double *, double *, int *);
+typedef int (*other3_t)(const double *, const double *, double *);
+
+static bool same_bits(const double *a, const double *b)
+{
+    for (int q = 0; q < 3; ++q) {
+        if (a[q] != a[q] && b[q] != b[q]) continue;   // NaN on both sides (payloads are not part of the contract)
+        if (std::memcmp(a + q, b + q, sizeof(double)) != 0) return false;
+    }
+    return true;
+}
+
+// n solves; staged != 0 runs this library's solve the way the pass kernel does (caps c1 -> c2 -> 50, every stage
+// continuing from the iterate the stage before stopped at).  Returns the number of solves whose verdict or final
+// iterate differs from other's; first_bad receives the index of the first one (or -1); converged the count.
+int64_t nh_compare(int64_t n, const double *pnts, const double *vtxs, void *other, int no_iters, int staged, int c1,
+                   int c2, int64_t *first_bad, int64_t *converged)
+{
+    int64_t bad = 0, conv = 0;
+    *first_bad = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = pnts + i * 3, *v = vtxs + i * 24;
+        double xo[3] = {0, 0, 0}, xm[3] = {0, 0, 0};
+        const int ok_o = no_iters ? ((other3_t)other)(p, v, xo) : ((other4_t)other)(p, v, xo, nullptr);
+        int ok_m;
+        if (staged) {
+            ok_m = nh_newton(p, v, xm, c1, 0);
+            if (!ok_m) ok_m = nh_newton(p, v, xm, c2, c1);
+            if (!ok_m) ok_m = nh_newton(p, v, xm, 50, c2);
+        } else {
+            ok_m = nh_newton(p, v, xm, 50, 0);
+        }
+        conv += ok_m;
+        if ((ok_o != 0) != (ok_m != 0) || !same_bits(xo, xm)) {
+            if (*first_bad < 0) *first_bad = i;
+            ++bad;
+        }
+    }
+    *converged = conv;
+    return bad;
+}
+}

@@ -1,0 +1,115 @@
+"""The kernels' hex8 Newton solve (multimesh_amd/csrc/mm_newton_hex8.h) compiled for the HOST and compared, iterate
+for iterate, with the CPU oracle and the compiled reference (trilinearinterpolator.c:260-305).
+
+The header restates the reference's expressions with fewer fp64 instructions (Jacobian carried at 8x, first trip
+specialised at xi = 0, exact-product fused multiply-adds); the claim is bit equality of every final iterate and every
+verdict, also when a solve is stopped at a cap and continued, the way locate_pass_kernel's tiers do it.  The same
+header is what the GPU kernels compile, so this runs without a GPU; the -m gpu parity tests then check the kernels."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host", "newton_host.cpp")
+HDR = os.path.join(HERE, "..", "multimesh_amd", "csrc", "mm_newton_hex8.h")
+OUT = os.path.join(HERE, "host", "_build", "libnewton_host.so")
+
+# corner (R, S, T) signs of trilinearinterpolator.c:8-10
+RST = np.array([[-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+
+
+@pytest.fixture(scope="module")
+def host():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-shared",
+                        "-o", OUT, SRC], check=True)
+    L = C.CDLL(OUT)
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags=["C_CONTIGUOUS"])
+    L.nh_compare.restype = C.c_int64
+    L.nh_compare.argtypes = [C.c_int64, f64p, f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.nh_newton.restype = C.c_int
+    L.nh_newton.argtypes = [f64p, f64p, f64p, C.c_int, C.c_int]
+    return L
+
+
+def elements(rng, n, jitter, scale, offset, spread):
+    """n hexahedra: the reference cube's corners, jittered, stretched per axis, moved to `offset`; one point each at
+    `spread` reference units (normal) around the centre."""
+    stretch = np.exp(rng.uniform(-1.0, 1.0, size=(n, 1, 3)))
+    vtx = (RST[None] + rng.uniform(-jitter, jitter, size=(n, 8, 3))) * stretch * (0.5 * scale)
+    pnt = vtx.mean(1) + rng.normal(scale=spread, size=(n, 3)) * stretch[:, 0] * (0.5 * scale)
+    off = np.asarray(offset, float)
+    return np.ascontiguousarray(pnt + off), np.ascontiguousarray(vtx + off)
+
+
+def compare(L, fn, no_iters, pnt, vtx, staged, c1=6, c2=9):
+    first, conv = C.c_int64(), C.c_int64()
+    bad = L.nh_compare(len(pnt), pnt, vtx, C.cast(fn, C.c_void_p), no_iters, staged, c1, c2, C.byref(first), C.byref(conv))
+    return bad, first.value, conv.value
+
+
+CASES = [
+    # jitter, scale, offset, spread of the points (reference units)
+    (0.25, 1.0, (0, 0, 0), 0.6),          # mildly distorted, points in and around the element
+    (0.45, 1.0, (0.3, -0.2, 0.1), 1.5),   # strongly distorted, many rejections and slow solves
+    (0.2, 29.5e3, (3.1e6, -2.2e6, 5.0e6), 0.8),   # Earth-scale coordinates in metres
+    (0.0, 1.0, (0, 0, 0), 0.7),           # affine elements: one update and the closing residual
+    (0.9, 1e-3, (1.0, 1.0, 1.0), 2.0),    # tangled elements far from the origin: divergence, caps, NaN
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_final_iterates_equal_the_oracle(host, case):
+    jitter, scale, offset, spread = CASES[case]
+    rng = np.random.default_rng(9000 + case)
+    pnt, vtx = elements(rng, 200_000, jitter, scale, offset, spread)
+    fn = O.lib().mmo_hex8_newton
+    for staged in (0, 1):
+        bad, first, conv = compare(host, fn, 0, pnt, vtx, staged)
+        assert bad == 0, (case, staged, first)
+    assert 0 < conv <= len(pnt)
+
+
+def test_every_cap_pair_continues_to_the_same_iterate(host):
+    rng = np.random.default_rng(77)
+    pnt, vtx = elements(rng, 20_000, 0.45, 1.0, (0, 0, 0), 1.2)
+    fn = O.lib().mmo_hex8_newton
+    for c1, c2 in [(1, 2), (2, 3), (3, 7), (5, 6), (6, 9), (1, 49)]:
+        bad, first, _ = compare(host, fn, 0, pnt, vtx, 1, c1, c2)
+        assert bad == 0, (c1, c2, first)
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_SO), reason="compiled reference not built")
+def test_final_iterates_equal_the_compiled_reference(host):
+    R = O.reference_lib()
+    rng = np.random.default_rng(5)
+    for case in (0, 1, 2):
+        jitter, scale, offset, spread = CASES[case]
+        pnt, vtx = elements(rng, 100_000, jitter, scale, offset, spread)
+        bad, first, _ = compare(host, R.inverseCoordinateTransform, 1, pnt, vtx, 1)
+        assert bad == 0, (case, first)
+
+
+def test_degenerate_inputs_give_the_same_verdicts(host):
+    # flat element (zero determinant), a point exactly at the centre, a point exactly on a corner, zero-size element
+    L = O.lib()
+    flat = RST.copy()
+    flat[:, 2] = 0.0
+    cube = RST.copy()
+    for vtx, pnt in [(flat, [0.1, 0.2, 0.0]), (cube, [0.0, 0.0, 0.0]), (cube, [1.0, 1.0, 1.0]), (cube * 0.0, [0.0, 0.0, 0.0]),
+                     (cube, [np.nan, 0.0, 0.0]), (cube * 1e-200, [1e-201, 0, 0])]:
+        vtx = np.ascontiguousarray(vtx, float)
+        pnt = np.ascontiguousarray(pnt, float)
+        a, b = np.zeros(3), np.zeros(3)
+        ok_o = L.mmo_hex8_newton(pnt, vtx, a, None)
+        ok_m = host.nh_newton(pnt, vtx, b, 50, 0)
+        assert bool(ok_o) == bool(ok_m)
+        assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(np.signbit(a), np.signbit(b)) or np.isnan(a).any()
