@@ -33,18 +33,20 @@
 #define MM_S(n) ((n) == 1 || (n) == 2 || (n) == 6 || (n) == 7 ? 1.0 : -1.0)
 #define MM_T(n) ((n) >= 4 ? 1.0 : -1.0)
 
-// Forward map of one axis (trilinearinterpolator.c:199-212) with named partials; each partial is
-// the same rounded quantity the reference's single expression produces.
-MM_HD double map_axis(const double (&v)[8], double hr, double hs, double ht)
+// Forward map of one axis (trilinearinterpolator.c:199-212).  The reference's factors are hr = 0.5 * (xi_0 + 1) etc.;
+// fr = xi_0 + 1 (the Jacobian needs it anyway) is passed instead and every partial is carried at twice its value:
+// e03 = hr * a03 = fl(fr * a03) / 2 exactly, and "x -/+ e03" becomes a fused multiply-add with the exact product
+// -/+0.5 * (2 e03) -- the same rounded quantity at every step of the reference's single expression.
+MM_HD double map_axis(const double (&v)[8], double fr, double fs, double ft)
 {
-    const double e03 = hr * (-v[0] + v[3]);
-    const double e12 = hr * (-v[1] + v[2]);
-    const double e45 = hr * (-v[4] + v[5]);
-    const double e76 = hr * (v[6] - v[7]);
-    const double bottom_s = hs * (((-v[0] + v[1]) - e03) + e12);
-    const double top_s = hs * (((-v[4] + v[7]) - e45) + e76);
-    const double along_t = ht * (((((-v[0] + v[4]) - e03) + e45) - bottom_s) + top_s);
-    return ((v[0] + e03) + bottom_s) + along_t;
+    const double e03 = fr * (-v[0] + v[3]);   // 2 x the reference's partial, like the next six
+    const double e12 = fr * (-v[1] + v[2]);
+    const double e45 = fr * (-v[4] + v[5]);
+    const double e76 = fr * (v[6] - v[7]);
+    const double bottom_s = fs * __builtin_fma(0.5, e12, __builtin_fma(-0.5, e03, -v[0] + v[1]));
+    const double top_s = fs * __builtin_fma(0.5, e76, __builtin_fma(-0.5, e45, -v[4] + v[7]));
+    const double along_t = ft * __builtin_fma(0.5, top_s, __builtin_fma(-0.5, bottom_s, __builtin_fma(0.5, e45, __builtin_fma(-0.5, e03, -v[0] + v[4]))));
+    return __builtin_fma(0.5, along_t, __builtin_fma(0.5, bottom_s, __builtin_fma(0.5, e03, v[0])));
 }
 
 // The same map at xi = 0 (hr = hs = ht = 0.5 exactly): e03 = a03 / 2 etc. are exact halvings, so every
@@ -65,17 +67,21 @@ MM_HD double map_axis_centre(const double (&v)[8])
 // (cofactor inverse trilinearinterpolator.c:320-359, update = (J^-1)^T * residual :362-375, each row summed from 0).
 MM_HD void newton_update(const double (&M)[3][3], double r0, double r1, double r2, double (&xi)[3])
 {
-    const double det = M[0][0] * (M[1][1] * M[2][2] - M[2][1] * M[1][2]) -
-                       M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    // the determinant's three cofactors are the first column of the adjugate: the reference writes the middle one as
+    // (m10 m22 - m12 m20) there and as (m12 m20 - m10 m22) here -- exact negatives of each other, so
+    // "- m01 * (m10 m22 - m12 m20)" is "+ m01 * c10" with the same roundings
+    const double c00 = M[1][1] * M[2][2] - M[2][1] * M[1][2];
+    const double c10 = M[1][2] * M[2][0] - M[1][0] * M[2][2];
+    const double c20 = M[1][0] * M[2][1] - M[2][0] * M[1][1];
+    const double det = M[0][0] * c00 + M[0][1] * c10 + M[0][2] * c20;
     const double rdet = 1 / det;
-    const double i00 = (M[1][1] * M[2][2] - M[2][1] * M[1][2]) * rdet;
+    const double i00 = c00 * rdet;
     const double i01 = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) * rdet;
     const double i02 = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) * rdet;
-    const double i10 = (M[1][2] * M[2][0] - M[1][0] * M[2][2]) * rdet;
+    const double i10 = c10 * rdet;
     const double i11 = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) * rdet;
     const double i12 = (M[1][0] * M[0][2] - M[0][0] * M[1][2]) * rdet;
-    const double i20 = (M[1][0] * M[2][1] - M[2][0] * M[1][1]) * rdet;
+    const double i20 = c20 * rdet;
     const double i21 = (M[2][0] * M[0][1] - M[0][0] * M[2][1]) * rdet;
     const double i22 = (M[0][0] * M[1][1] - M[1][0] * M[0][1]) * rdet;
     const double u0 = ((0. + i00 * r0) + i10 * r1) + i20 * r2;   // the reference's update / 8
@@ -135,18 +141,16 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
         it = 1;
     }
     for (; it < max_it; ++it) {
-        const double hr = 0.5 * (xi[0] + 1.0);
-        const double hs = 0.5 * (xi[1] + 1.0);
-        const double ht = 0.5 * (xi[2] + 1.0);
-        const double r0 = px - map_axis(x, hr, hs, ht);
-        const double r1 = py - map_axis(y, hr, hs, ht);
-        const double r2 = pz - map_axis(z, hr, hs, ht);
-        if (__builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol) return true;  // z is never tested (reference quirk)
-        // the reference's factors xi * (+-1) + 1 (two values per axis) and their pairwise products: dN_n/dxi_0 =
-        // 0.125 R_n fs ft is an exact scaling of fl(fs ft), the same for the other two
+        // the reference's factors xi * (+-1) + 1 (two values per axis)
         const double fr[2] = {-xi[0] + 1, xi[0] + 1};
         const double fs[2] = {-xi[1] + 1, xi[1] + 1};
         const double ft[2] = {-xi[2] + 1, xi[2] + 1};
+        const double r0 = px - map_axis(x, fr[1], fs[1], ft[1]);
+        const double r1 = py - map_axis(y, fr[1], fs[1], ft[1]);
+        const double r2 = pz - map_axis(z, fr[1], fs[1], ft[1]);
+        if (__builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol) return true;  // z is never tested (reference quirk)
+        // ... and their pairwise products: dN_n/dxi_0 = 0.125 R_n fs ft is an exact scaling of fl(fs ft), the same for
+        // the other two
         double gst[2][2], grt[2][2], grs[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
