@@ -92,6 +92,17 @@ struct mm_context {
     bool ev_used[MM_STAGE_COUNT];
     bool ev_created = false;
     hipEvent_t ev_misc = nullptr;   // host waits on small readbacks while later work stays queued
+    // mm_interpolate_hex8: the bounding box of the previous call's centroids (one level, default density), from which
+    // the next call over a source mesh of the same size lays its search grid out without waiting for its own box
+    // (mm_knn_build_guessed / mm_knn_guess_confirmed in mm_knn.hip); misses: calls that had to be run again
+    struct {
+        bool valid = false;
+        i64 nsrc = 0;
+        double box[6] = {0, 0, 0, 0, 0, 0};
+        int stat_shift = -1;
+        int misses = 0;
+        long long calls_guessed = 0;   // (mm_debug_grid_guess: what the tests look at)
+    } grid_guess;
     hipStream_t copy_stream = nullptr;   // host-array entry points: uploads run beside the kernels (created on first use)
     hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr};
 };
@@ -104,6 +115,13 @@ static inline size_t mm_round256(size_t b) { return (b + 255) & ~(size_t)255; }
 // bytes to clear for a carve of `b` bytes: whole 256-byte units (the carve is rounded up to them, and an odd
 // tail costs a second fill dispatch) -- except under MM_GUARD_ALLOC, where the carve ends with its array
 static inline size_t mm_fill_span(size_t b) { return mm_guard_alloc() ? b : mm_round256(b); }
+
+// Zero `bytes` bytes of device memory on ctx->stream with a kernel of the library's own (see mm_context.hip: the runtime's
+// fill is queued behind a barrier).
+int mm_zero_async(mm_context *ctx, void *dst_d, size_t bytes);
+
+// n (<= 64) 64-bit words of device memory into the context's pinned mirror, by a kernel on ctx->stream.
+int mm_mirror_async(mm_context *ctx, long long *dst_pinned, const long long *src_d, int n);
 
 // Cached buffer of at least `bytes` for `slot` (grows by reallocation, after a stream sync).
 int mm_buffer_get(mm_context *ctx, int slot, size_t bytes, void **out);

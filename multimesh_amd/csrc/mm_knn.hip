@@ -155,6 +155,30 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double ih, int n)
     return (int)t;
 }
 
+// The histogram atomic also hands out the item's rank inside its cell, so the scatter pass needs
+// no second atomic.  Mesh-ordered points arrive in runs of equal cells (neighbours along the
+// fastest axis), and same-address atomics serialise in L2: the first lane of each run of equal
+// cells inside the wave adds the run's length, the others take consecutive ranks behind it.
+// (Random-order input: every run has length 1, nothing lost but a dozen instructions.)
+// Called by every lane of the wave (c = -1, live = false for lanes without an item).
+__device__ __forceinline__ int count_and_rank(int c, bool live, int *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
+    const int head_lane = 63 - __clzll((long long)upto);
+    const unsigned long long after = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+    int base = 0;
+    if (head && live) {
+        const int next_head = after ? __ffsll((long long)after) - 1 : 64;
+        base = atomicAdd(&counts[c], next_head - lane);
+    }
+    base = __shfl(base, head_lane);
+    return base + (lane - head_lane);
+}
+
 // With `list` the items are the points list[0 .. *list_count) (a density level's share of the targets).
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
                                                             GridParams g, int2 *__restrict__ cell_of,
@@ -174,25 +198,8 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__rest
         const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
         c = (cx * g.ny + cy) * g.nz + cz;
     }
-    // The histogram atomic also hands out the item's rank inside its cell, so the scatter pass needs
-    // no second atomic.  Mesh-ordered points arrive in runs of equal cells (neighbours along the
-    // fastest axis), and same-address atomics serialise in L2: the first lane of each run of equal
-    // cells inside the wave adds the run's length, the others take consecutive ranks behind it.
-    // (Random-order input: every run has length 1, nothing lost but a dozen instructions.)
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(c, 1);
-    const bool head = lane == 0 || c != prev;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long upto = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
-    const int head_lane = 63 - __clzll((long long)upto);
-    const unsigned long long after = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
-    int base = 0;
-    if (head && live) {
-        const int next_head = after ? __ffsll((long long)after) - 1 : 64;
-        base = atomicAdd(&counts[c], next_head - lane);
-    }
-    base = __shfl(base, head_lane);
-    if (live) cell_of[e] = make_int2(c, base + (lane - head_lane));
+    const int rank = count_and_rank(c, live, counts);
+    if (live) cell_of[e] = make_int2(c, rank);
 }
 
 // ---- exclusive scan of the per-cell counts (three small kernels) --------------------
@@ -267,8 +274,15 @@ __global__ __launch_bounds__(kBlock) void scan_tile_sums_kernel(const int *__res
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kBlock) void scan_tile_offsets_kernel(int *__restrict__ tile_sums, int ntiles)
+// mirror_src / mirror_dst (nullable): mirror_n 64-bit words copied on the way from device memory to the context's
+// PINNED host mirror -- the grid statistic the kernel before this one accumulated (a copy command of the runtime's costs a
+// dispatch of 4 us behind a 6 us gap)
+__global__ __launch_bounds__(kBlock) void scan_tile_offsets_kernel(int *__restrict__ tile_sums, int ntiles,
+                                                                    const long long *__restrict__ mirror_src = nullptr,
+                                                                    long long *__restrict__ mirror_dst = nullptr,
+                                                                    int mirror_n = 0)
 {
+    if (mirror_src && (int)threadIdx.x < mirror_n) mirror_dst[threadIdx.x] = mirror_src[threadIdx.x];
     // single block: running exclusive scan over the tile sums
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -2689,9 +2703,32 @@ int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start,
 // cell into 32-byte records.  With level_extra != null the share of sources in well-filled cells is
 // read back (while the scan and the scatter are still queued, so a uniform cloud pays no idle time
 // for it) and *level_extra = the number of denser levels the cloud asks for.
+// The grid statistic in the pinned mirror (valid once the stream has passed the copy build_level queues): which denser
+// levels the build wants -- bit l-1 set: level l (band mass = difference of the cumulative shares) -- and how many
+// sources sit in sparse cells.
+static int stat_verdict(const mm_context *ctx, i64 nsrc, int sample_shift, double *sparse_count)
+{
+    int extra = 0;
+    for (int b = 0; b < kMaxLevels - 1; ++b) {
+        const double above = (double)ctx->h_counters[kStatSlot + b];
+        const double next = b + 1 < kMaxLevels - 1 ? (double)ctx->h_counters[kStatSlot + b + 1] : 0.0;
+        if (above - next > kLevelShare * (double)nsrc) extra |= 1 << b;
+    }
+    *sparse_count = (double)ctx->h_counters[kStatSlot + kMaxLevels - 1] * (double)(1 << sample_shift);
+    return extra;
+}
+
+// A build over a GUESSED grid (mm_knn_build_guessed): nobody waits for the bounding box or the grid statistic; the box
+// is reduced into the pinned mirror on the way and *stat_shift tells mm_knn_guess_confirmed how the statistic was sampled.
+struct GuessedBuild {
+    const double *box_partial;
+    int box_nblocks;
+    int *stat_shift;
+};
+
 static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
                        bool use_context_buffers, int level, int *level_extra, mm_knn_index **out,
-                       double *sparse_share = nullptr, bool stat_dirty = true)
+                       double *sparse_share = nullptr, bool stat_dirty = true, const GuessedBuild *guessed = nullptr)
 {
     static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
     const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
@@ -2773,9 +2810,13 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         return MM_ERR_ALLOC;
     }
     // (whole 256-byte units -- the carve is rounded up to them --: an odd tail costs a second fill dispatch)
-    e = hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream);
-    if (e != hipSuccess) { mm_set_error(MM_ERR_HIP, "memset: %s", hipGetErrorString(e)); free_index(ix); return MM_ERR_HIP; }
+    rc = mm_zero_async(ctx, counts, mm_fill_span((size_t)(ncells + 1) * sizeof(int)));
+    if (rc != MM_OK) { free_index(ix); return rc; }
     const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
+    if (guessed)   // this call's own box goes to the pinned mirror, where mm_knn_guess_confirmed finds it at the end of the call
+        hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, guessed->box_partial, guessed->box_nblocks,
+                           reinterpret_cast<double *>(ctx->h_counters + kBoxSlot),
+                           reinterpret_cast<long long *>(ctx->d_counters + kStatSlot));
     if (nsrc > 0)
         hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            counts, (const int *)nullptr, (const int *)nullptr);
@@ -2791,9 +2832,12 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     if (e == hipSuccess)
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                            want_stat ? (unsigned long long *)stat : (unsigned long long *)nullptr, sample_shift);
+    // (the scan's second kernel writes the statistic to the pinned mirror on its way; the host waits for it -- ev_misc --
+    // only after the rest of the build is queued, or not at all: mm_knn_build_guessed)
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles,
+                       want_stat ? (const long long *)stat : (const long long *)nullptr,
+                       (long long *)(ctx->h_counters + kStatSlot), want_stat ? kMaxLevels : 0);
     if (want_stat) {
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(ctx->h_counters + kStatSlot, stat, kMaxLevels * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
@@ -2801,7 +2845,6 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
             return MM_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                        ix->cell_start);
     if (nsrc > 0)
@@ -2813,20 +2856,16 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         free_index(ix);
         return MM_ERR_HIP;
     }
-    if (want_stat) {
+    if (guessed) *guessed->stat_shift = want_stat ? sample_shift : -1;
+    if (want_stat && !guessed) {
         e = hipEventSynchronize(ctx->ev_misc);
         if (e != hipSuccess) {
             mm_set_error(MM_ERR_HIP, "grid statistic: %s", hipGetErrorString(e));
             free_index(ix);
             return MM_ERR_HIP;
         }
-        // bit l-1 set: level l is wanted (band mass = difference of the cumulative shares)
-        for (int b = 0; b < kMaxLevels - 1; ++b) {
-            const double above = (double)ctx->h_counters[kStatSlot + b];
-            const double next = b + 1 < kMaxLevels - 1 ? (double)ctx->h_counters[kStatSlot + b + 1] : 0.0;
-            if (above - next > kLevelShare * (double)nsrc) *level_extra |= 1 << b;
-        }
-        const double sparse_count = (double)ctx->h_counters[kStatSlot + kMaxLevels - 1] * (double)(1 << sample_shift);
+        double sparse_count = 0.0;
+        *level_extra = stat_verdict(ctx, nsrc, sample_shift, &sparse_count);
         if (sparse_share) *sparse_share = sparse_count / (double)nsrc;
         static const bool dbg_build = getenv("MM_KNN_DEBUG") != nullptr;
         if (dbg_build) {
@@ -2889,7 +2928,9 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
     mm_knn_index *head = nullptr;
     static const double sparse_limit = getenv("MM_KNN_SPARSE_SHARE") ? atof(getenv("MM_KNN_SPARSE_SHARE")) : kSparseShare;
     int rc = MM_OK;
+    double per_cell_level0 = per_cell;
     for (int scale = 1;; scale *= 2) {
+        per_cell_level0 = per_cell;
         double sparse = 0.0;
         rc = build_level(ctx, src_d, nsrc, (int)ndim, box, per_cell, use_context_buffers, 0, max_levels > 1 ? &extra : nullptr,
                          &head, &sparse, /*stat_dirty=*/scale > 1 || nsrc == 0);
@@ -2914,7 +2955,49 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         tail = lvl;
     }
     *out = head;
+    // the fused pipeline's next call over a source mesh of this size may start from this grid (mm_knn_build_guessed):
+    // only the plain case -- one level, laid out at the default density
+    if (use_context_buffers && box_partial_d && ndim == 3) {
+        ctx->grid_guess.valid = !head->fine && extra == 0 && per_cell_level0 == kDefaultPerCell && max_levels > 1;
+        ctx->grid_guess.nsrc = nsrc;
+        for (int q = 0; q < 6; ++q) ctx->grid_guess.box[q] = box[q];
+    }
     return MM_OK;
+}
+
+// The fused pipeline's build when the context remembers the grid of its previous call over a source mesh of the same
+// size (ctx->grid_guess: the bounding box of the centroids; reference scripts/cli.py:183-195 and every time loop
+// interpolate from ONE source mesh again and again).  The grid is laid out from the remembered box, nothing waits for
+// this call's box or the grid statistic in mid-call (two host round trips with an idle GPU behind each), and
+// mm_knn_guess_confirmed compares both with the guess after the call's last synchronisation -- a different box or a
+// statistic that asks for density levels or a coarser grid means the call is run again the ordinary way (the kernels
+// are safe on any grid: cell coordinates are clamped).  (Counting the cells inside the centroid kernel as well was
+// measured: that kernel grows by what cell_count_kernel takes on its own, 68 vs 57 us -- the atomics and ranks, not
+// the second read of the centroids, are its cost.)
+int mm_knn_build_guessed(mm_context *ctx, const double *cen, i64 nelem, const double *box_partial, int box_nblocks,
+                         mm_knn_index **out)
+{
+    *out = nullptr;
+    GuessedBuild gb;
+    gb.box_partial = box_partial;
+    gb.box_nblocks = box_nblocks;
+    gb.stat_shift = &ctx->grid_guess.stat_shift;
+    int extra = 0;
+    double sparse = 0.0;
+    return build_level(ctx, cen, nelem, 3, ctx->grid_guess.box, kDefaultPerCell, true, 0, &extra, out, &sparse,
+                       /*stat_dirty=*/false, &gb);
+}
+
+// After the synchronisation that ends a call built by mm_knn_build_guessed: was the guess this call's own grid?
+bool mm_knn_guess_confirmed(mm_context *ctx)
+{
+    const double *h_box = reinterpret_cast<const double *>(ctx->h_counters + kBoxSlot);
+    if (memcmp(h_box, ctx->grid_guess.box, 6 * sizeof(double)) != 0) return false;
+    if (ctx->grid_guess.stat_shift < 0) return true;   // (a mesh too small for the statistic: the ordinary build skips it too)
+    double sparse_count = 0.0;
+    static const double sparse_limit = getenv("MM_KNN_SPARSE_SHARE") ? atof(getenv("MM_KNN_SPARSE_SHARE")) : kSparseShare;
+    const int extra = stat_verdict(ctx, ctx->grid_guess.nsrc, ctx->grid_guess.stat_shift, &sparse_count);
+    return extra == 0 && !(sparse_count / (double)ctx->grid_guess.nsrc > sparse_limit);
 }
 
 // tsorted_out (nullable): the caller can take the rows in the cell-sorted order of the targets; on return
@@ -3036,8 +3119,10 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         }
     }
     const bool one_fill = !force_list && (char *)counts0 == (char *)fb_count + 256 * (size_t)(1 + nlevels);   // (not so under MM_GUARD_ALLOC)
-    MM_HIP_CHECK(hipMemsetAsync(fb_count, 0, 256 * (size_t)(1 + nlevels) + (one_fill ? mm_round256((size_t)(ix->ncells + 1) * sizeof(int)) : 0),
-                                ctx->stream));
+    {
+        const int zrc = mm_zero_async(ctx, fb_count, 256 * (size_t)(1 + nlevels) + (one_fill ? mm_round256((size_t)(ix->ncells + 1) * sizeof(int)) : 0));
+        if (zrc != MM_OK) return zrc;
+    }
     const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
     const int *list = list0, *list_count = list0_count;   // level 0: every target (or the caller's list)
     int level = 0;
@@ -3070,7 +3155,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             return MM_ERR_ALLOC;
         }
         if (!(level == 0 && one_fill))
-            MM_HIP_CHECK(hipMemsetAsync(counts, 0, mm_fill_span((size_t)(ncells + 1) * sizeof(int)), ctx->stream));
+            if (mm_zero_async(ctx, counts, mm_fill_span((size_t)(ncells + 1) * sizeof(int))) != MM_OK) return MM_ERR_HIP;
         hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
                            counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,

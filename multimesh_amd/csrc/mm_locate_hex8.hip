@@ -605,7 +605,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     // second pass's) sit in one block of the context's counter array (mm_common.h): ONE fill clears both
     int *counters = reinterpret_cast<int *>(ctx->d_counters + 8);
     if (d_nfailed == ctx->d_counters) {
-        MM_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(i64), ctx->stream));
+        if (mm_zero_async(ctx, ctx->d_counters, 16 * sizeof(i64)) != MM_OK) return MM_ERR_HIP;
     } else {
         MM_HIP_CHECK(hipMemsetAsync(d_nfailed, 0, sizeof(i64), ctx->stream));
         MM_HIP_CHECK(hipMemsetAsync(counters, 0, 16 * sizeof(int), ctx->stream));

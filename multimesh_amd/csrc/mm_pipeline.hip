@@ -13,6 +13,9 @@ int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts
 int mm_knn_query_sorted_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, int *idx_d,
                              const double **tsorted_out);
 void mm_clear_status(void);
+int mm_knn_build_guessed(mm_context *ctx, const double *cen, i64 nelem, const double *box_partial, int box_nblocks,
+                         mm_knn_index **out);
+bool mm_knn_guess_confirmed(mm_context *ctx);
 
 // candidates delivered up front when the lists are evaluated lazily (99.9 % of mesh-node targets are
 // resolved within them; see mm_set_lazy_lists)
@@ -75,6 +78,7 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     int64_t result = MM_ERR_HIP;
     hipError_t e = hipSuccess;
     int rc = MM_OK;
+    bool guessed = false;
 
 #define MM_PIPE_FAIL(code, msg)                                        \
     do {                                                               \
@@ -115,6 +119,15 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     // scripts/cli.py:77-78): the reference-order locate kernel, the only place a point can fail,
     // writes them (no 1.3 GB memset up front)
 
+    // The search grid is laid out from the bounding box of the centroids, which the host would have to wait for in
+    // mid-call.  When the previous call of this context left the box of a source mesh of the same size (the usual
+    // case: one source mesh, many calls), the grid is GUESSED from that box and the guess is checked against this
+    // call's own box after the synchronisation that ends the call; a wrong
+    // guess runs the call again the ordinary way (twice wrong: no more guessing in this context).  MM_GRID_GUESS=0
+    // switches it off.
+    static const bool guess_on = !(getenv("MM_GRID_GUESS") && atoi(getenv("MM_GRID_GUESS")) == 0);
+    guessed = guess_on && ctx->grid_guess.valid && ctx->grid_guess.nsrc == nelem && ctx->grid_guess.misses < 2;
+again:
     if (feed && (rc = feed_upload(ctx, feed, 0, 1, 0)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
     rc = mm_launch_centroid_bbox(ctx, nelem, (const i64 *)conn_d, nodes_d, cen, box_partial, kBoxBlocks);
@@ -122,7 +135,12 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true, box_partial, kBoxBlocks);
+    if (guessed) {
+        ++ctx->grid_guess.calls_guessed;
+        rc = mm_knn_build_guessed(ctx, cen, nelem, box_partial, kBoxBlocks, &index);
+    } else {
+        rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true, box_partial, kBoxBlocks);
+    }
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     if (rc != MM_OK) { result = rc; goto done; }
 
@@ -156,9 +174,21 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
         if (rc != MM_OK) { result = rc; goto done; }
     }
 
-    e = hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    rc = mm_mirror_async(ctx, (long long *)ctx->h_counters, (const long long *)ctx->d_counters, 1);
+    if (rc != MM_OK) { result = rc; goto done; }
+    e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) MM_PIPE_FAIL(MM_ERR_HIP, hipGetErrorString(e));
+    if (guessed && !mm_knn_guess_confirmed(ctx)) {
+        // not this mesh's grid: everything again, the ordinary way (which also leaves the right box for the next call)
+        ctx->grid_guess.valid = false;
+        ++ctx->grid_guess.misses;
+        guessed = false;
+        mm_knn_destroy(nullptr, index);
+        index = nullptr;
+        feed = nullptr;   // (the device copies of host arrays are in place)
+        mm_stage_reset(ctx);
+        goto again;
+    }
     result = ctx->h_counters[0];
 
 done:
@@ -166,6 +196,18 @@ done:
     if (index) mm_knn_destroy(nullptr, index);  // borrowed arrays stay in the context cache
     return result;
 #undef MM_PIPE_FAIL
+}
+
+// Debugging aid (not part of the drop-in surface): out4 = {a guess is held, calls that had to be run again, calls
+// started from a guess, source elements of the guess}.
+extern "C" int mm_debug_grid_guess(mm_context *ctx, long long *out4)
+{
+    MM_REQUIRE(ctx != nullptr && out4 != nullptr, "null argument");
+    out4[0] = ctx->grid_guess.valid ? 1 : 0;
+    out4[1] = ctx->grid_guess.misses;
+    out4[2] = ctx->grid_guess.calls_guessed;
+    out4[3] = ctx->grid_guess.nsrc;
+    return MM_OK;
 }
 
 extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnodes,

@@ -1,0 +1,121 @@
+"""The fused pipeline's guessed search grid (mm_interpolate_hex8: the grid laid out from the PREVIOUS call's bounding
+box, checked against this call's own box at the end, the call run again on a miss): a guessed call, a call whose
+guess was wrong, and a call with the guess switched off all return what a fresh context returns, bit for bit, and the
+debug counters show which path ran.  Reference flow: scripts/cli.py:62-100 (one source mesh, many calls: :183-195)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from multimesh_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _guess_state(ctx):
+    out = (C.c_longlong * 4)()
+    fn = ctx.lib.mm_debug_grid_guess
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    assert fn(ctx.handle, out) == 0
+    return {"valid": out[0], "misses": out[1], "guessed": out[2], "nsrc": out[3]}
+
+
+def _fresh(pa, ca, pb, fields):
+    from multimesh_amd.device import Context
+
+    c = Context(0)
+    try:
+        v, enc, w, nf = c.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+        assert _guess_state(c)["guessed"] == 0           # a context's first call has nothing to guess from
+        return v.numpy(), enc.numpy(), w.numpy(), nf
+    finally:
+        c.close()
+
+
+def test_guessed_call_hit_miss_and_recovery():
+    from multimesh_amd.device import Context
+
+    n = 30
+    pa, ca = synth.hex_mesh(n, seed=1, jitter=0.3)
+    pb = np.random.default_rng(5).uniform(0.02, 0.98, size=(40_000, 3))
+    fields = synth.vector_field(pa)[:2]
+    ref = _fresh(pa, ca, pb, fields)
+    # the same element count in another place and size: the guess left by mesh A is wrong for it
+    pa2 = pa * 1.5 + np.array([3.0, -1.0, 0.25])
+    pb2 = pb * 1.5 + np.array([3.0, -1.0, 0.25])
+    fields2 = synth.vector_field(pa2)[:2]
+    ref2 = _fresh(pa2, ca, pb2, fields2)
+
+    c = Context(0)
+    try:
+        def run(p, q, f):
+            v, enc, w, nf = c.interpolate_hex8(p, ca, q, f, nelem_to_search=20, want_operator=True)
+            return v.numpy(), enc.numpy(), w.numpy(), nf
+
+        def same(a, b):
+            return a[3] == b[3] and all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+
+        assert same(run(pa, pb, fields), ref)
+        s = _guess_state(c)
+        assert s == {"valid": 1, "misses": 0, "guessed": 0, "nsrc": len(ca)}
+        assert same(run(pa, pb, fields), ref)            # guessed, confirmed
+        sub = run(pa, pb[::3].copy(), fields)            # guessed, confirmed: other targets, same source mesh
+        assert sub[3] == 0 and all(np.array_equal(x, y[::3]) for x, y in zip(sub[:3], ref[:3]))
+        s = _guess_state(c)
+        assert s["guessed"] == 2 and s["misses"] == 0 and s["valid"] == 1
+        assert same(run(pa2, pb2, fields2), ref2)        # guessed from mesh A's box: wrong, run again
+        s = _guess_state(c)
+        assert s["guessed"] == 3 and s["misses"] == 1 and s["valid"] == 1   # (the second run left mesh B's box)
+        assert same(run(pa2, pb2, fields2), ref2)        # guessed from mesh B's box: right
+        s = _guess_state(c)
+        assert s["guessed"] == 4 and s["misses"] == 1
+        assert same(run(pa, pb, fields), ref)            # second miss: this context stops guessing
+        s = _guess_state(c)
+        assert s["guessed"] == 5 and s["misses"] == 2
+        assert same(run(pa, pb, fields), ref)
+        assert _guess_state(c)["guessed"] == 5
+    finally:
+        c.close()
+
+
+def test_values_only_and_host_entry_after_a_guess():
+    from multimesh_amd.device import Context
+
+    pa, ca = synth.hex_mesh(24, seed=2, jitter=0.25)
+    pb, _ = synth.hex_mesh(31, seed=7, jitter=0.2)
+    fields = synth.vector_field(pa)[:1]
+    c = Context(0)
+    try:
+        v0, nf0 = c.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+        v1, nf1 = c.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+        out = c.interpolate_hex8_host(pa, ca, pb, fields, nelem_to_search=20)
+        assert _guess_state(c)["guessed"] == 2 and _guess_state(c)["misses"] == 0
+        assert nf0 == nf1 == out[-1]
+        assert np.array_equal(v0.numpy(), v1.numpy()) and np.array_equal(v0.numpy(), np.asarray(out[0]))
+    finally:
+        c.close()
+
+
+def test_switch_off():
+    code = (
+        "import numpy as np, ctypes as C\n"
+        "from multimesh_amd import synth\n"
+        "from multimesh_amd.device import Context\n"
+        "pa, ca = synth.hex_mesh(16, seed=1, jitter=0.3)\n"
+        "pb = np.random.default_rng(5).uniform(0.05, 0.95, size=(5000, 3))\n"
+        "f = synth.vector_field(pa)[:1]\n"
+        "c = Context(0)\n"
+        "a = c.interpolate_hex8(pa, ca, pb, f)[0].numpy(); b = c.interpolate_hex8(pa, ca, pb, f)[0].numpy()\n"
+        "out = (C.c_longlong * 4)(); c.lib.mm_debug_grid_guess.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]\n"
+        "c.lib.mm_debug_grid_guess(c.handle, out)\n"
+        "assert np.array_equal(a, b) and out[2] == 0, list(out)\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, MM_GRID_GUESS="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
