@@ -271,6 +271,13 @@ constexpr int kPassBlock = 256;
 // slowest tier first: tiers 1 and 2 only grow in rounds of the tier below, which run while they hold fewer
 // than 64 (< 128 after the round); tier 0 grows in every round -- 63 + 64 from its own rounds, then one
 // round each of tiers 1 and 2 before it is served again: < 256.
+// Batches of one plane per panel of the walk order (see the kernel; MM_LOCATE_PANEL overrides, 0 = in order).  -1: as many
+// as the XCD has waves in the launch -- wave w then takes column w of a panel in plane after plane: its consecutive
+// batches are neighbours ACROSS planes (the same strip of cells, one plane on), which share a layer of elements, and the
+// front of all waves is one plane's slice of the panel.  Measured on the metric meshes (locate pass, ms): in order 1.536,
+// panels of 64 / 128 / 192 / 384: 1.52 / 1.53 / 1.53 / 1.54, of 256 (= the waves of an XCD) / 512 / 1024 / 2048:
+// 1.48 / 1.49 / 1.49 / 1.49.
+constexpr int kPassPanel = -1;
 constexpr int kWaveQueue0 = 256;
 constexpr int kWaveQueue = 128;
 
@@ -326,7 +333,8 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                                                                  int *__restrict__ slow_list,
                                                                  int *__restrict__ slow_count,
                                                                  const int *__restrict__ in_list,
-                                                                 const int *__restrict__ in_count, int j0)
+                                                                 const int *__restrict__ in_count, int j0,
+                                                                 int planes = 0, int panel = 0)
 {
     // in_list (nullable, not with SORTED): only the targets in_list[0 .. *in_count), each from candidate j0 on -- the second
     // pass over the targets that exhausted their lazily evaluated candidates, on their full lists (nn then holds k = the
@@ -356,7 +364,49 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
     const i64 total = b_hi * 64 < npoints ? b_hi * 64 : npoints;       // end of this XCD's range
     const i64 nwaves = (i64)((gridDim.x - xcd + nx - 1) / nx) * (kPassBlock / 64);   // waves of this XCD
     const i64 wave = (i64)(blockIdx.x / nx) * (kPassBlock / 64) + (threadIdx.x >> 6);
-    i64 next = (b_lo + wave) * 64;  // first target of this wave's next fresh batch
+    // Order of the fresh batches inside the XCD's range (SORTED only; planes = x-planes of cells the whole sorted order
+    // spans, panel > 0).  In sorted order the front of the XCD's waves sweeps one x-plane of cells after the other, and
+    // the connectivity rows and nodes shared with the NEXT plane have left the 4 MiB L2 when that plane comes round
+    // (a plane of the metric mesh touches ~9 MB of mesh: every line crossed the fabric 2.2 times).  So the range is
+    // read as `rows` planes of `cols` batches each and walked panel by panel: `panel` neighbouring batches of every
+    // plane in turn, then the next panel -- the front then spans a few planes of one narrow strip, whose mesh lines
+    // stay resident.  Any bijection of the batches is correct; when the planes hold unequal numbers of targets the
+    // rows are only roughly the planes and the order is merely less local.  seq -> batch below; sequence numbers
+    // that fall outside the range (the last panel, the last row) are skipped.
+    // (everything here is wave-uniform and fits 32 bits: npoints < 2^31; kept in scalar registers)
+    const int nb_x = (int)(b_hi - b_lo);
+    int rows = 1, cols = nb_x, seq_end = nb_x;
+    if (panel < 0) panel = (int)nwaves;   // the default: see kPassPanel
+    if (SORTED && planes > 0 && panel > 0 && !in_list) {
+        rows = (int)(((i64)planes * nb_x + nbatches / 2) / nbatches);
+        rows = rows < 1 ? 1 : rows;
+        cols = (nb_x + rows - 1) / rows;
+        const i64 se = (i64)((cols + panel - 1) / panel) * panel * rows;
+        if (se < (i64)0x7fffffff - 4 * (i64)nwaves) seq_end = (int)se;
+        else rows = 1;   // (never: < 2^25 batches)
+    }
+    const int seq_step = (int)nwaves;
+    int seq = __builtin_amdgcn_readfirstlane((int)wave);   // this wave's next sequence number
+    i64 next = total;  // first target of this wave's next fresh batch (total: none left)
+    auto advance = [&]() {
+        next = total;
+        for (; seq < seq_end; seq += seq_step) {
+            int b = seq;
+            if (rows > 1) {
+                const unsigned per_panel = (unsigned)rows * (unsigned)panel;
+                const unsigned pnl = (unsigned)seq / per_panel, rem = (unsigned)seq - pnl * per_panel;
+                const unsigned row = rem / (unsigned)panel, col = pnl * (unsigned)panel + (rem - row * (unsigned)panel);
+                if (col >= (unsigned)cols) continue;
+                b = (int)(row * (unsigned)cols + col);
+            }
+            if (b < nb_x) {
+                next = (b_lo + b) * 64;
+                seq += seq_step;
+                break;
+            }
+        }
+    };
+    advance();
 #ifdef MM_LOCATE_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
@@ -398,7 +448,7 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             active = q < total;
             if (active) i = in_list ? (i64)in_list[q] : q;
             j = j0;
-            next += nwaves * 64;
+            advance();
         } else if (held0 > 0) {
             // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
             // handful of short rounds at the very end of the pass instead of another pass).  The idle
@@ -645,9 +695,13 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         // below works on the targets' own indices either way)
         // (node ids in 32 bits when the caller has told us how many nodes there are: fewer registers across the solve)
         const bool nid32 = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
+        // (walk order of the sorted targets: see the kernel; the kNN grid's x dimension comes with the lazy lists)
+        static const int panel_env = getenv("MM_LOCATE_PANEL") ? atoi(getenv("MM_LOCATE_PANEL")) : kPassPanel;
+        const int planes = (tsorted && lazy && lazy->index && !lazy->index->fine) ? lazy->index->dims[0] : 0;
+        const int panel = panel_env;   // (0: in order, < 0: the kernel's default)
 #define MM_PASS_LAUNCH(EX, SO, NID, P)                                                                                  \
     hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, SO, NID>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, \
-                       nodes, P, slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0)
+                       nodes, P, slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel)
         if (tsorted && conn_is_exodus) {
             if (nid32) MM_PASS_LAUNCH(true, true, int, tsorted);
             else MM_PASS_LAUNCH(true, true, i64, tsorted);
