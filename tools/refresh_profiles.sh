@@ -19,6 +19,7 @@ step pmc traffic
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1 || exit 1
 python3 tools/make_traffic_profile.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null || exit 1
+[ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json   # (the bench lines' `traffic` reads it)
 step counters
 bash tools/knn_counters.sh $O/knn_counters.json > $O/counters.log 2>&1
 MM_COUNTER_ARGS="bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline" MM_COUNTER_VALU_ONLY=1 \
