@@ -38,14 +38,6 @@
 #include "mm_common.h"
 #include "mm_newton_hex8.h"
 
-#ifdef MM_NO_STREAM_HINTS
-#define MM_STREAM_LOAD(p) (*(p))
-#define MM_STREAM_STORE(p, v) (*(p) = (v))
-#else
-#define MM_STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#define MM_STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#endif
-
 namespace {
 
 // map_axis, newton_hex8 and the corner signs MM_R / MM_S / MM_T: mm_newton_hex8.h (shared with the host-side test of
@@ -163,8 +155,7 @@ __device__ __forceinline__ void emit_row(const Emit &em, i64 i, const ID (&id)[8
 #pragma unroll
             for (int n = 0; n < 8; ++n) p[n] = f[sid[n]] * wt[n];
             // 0.0 + ...: NumPy starts the reduction from the identity (a row sum of -0.0 reads +0.0)
-            // (written once, read by nobody in this launch: a streaming store, so that it does not push mesh lines out of L2)
-            MM_STREAM_STORE(em.out + (i * em.ncomp + c), 0.0 + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))));
+            em.out[i * em.ncomp + c] = 0.0 + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
         }
     }
 }
@@ -507,12 +498,11 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             double px, py, pz;
             if (SORTED) {
                 const double2 *r2 = reinterpret_cast<const double2 *>(pts + i * 4);
-                // (the records and the candidate rows stream through once or twice: marked non-temporal, the mesh lines
-                // the neighbouring targets share are what the L2 is for)
-                px = MM_STREAM_LOAD(&r2[0].x);
-                py = MM_STREAM_LOAD(&r2[0].y);
-                pz = MM_STREAM_LOAD(&r2[1].x);
-                tid = (i64)(int)__double_as_longlong(MM_STREAM_LOAD(&r2[1].y));
+                const double2 xy = r2[0], zw = r2[1];
+                px = xy.x;
+                py = xy.y;
+                pz = zw.x;
+                tid = (i64)(int)__double_as_longlong(zw.y);
             } else {
                 px = pts[i * 3 + 0];
                 py = pts[i * 3 + 1];
@@ -526,7 +516,7 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             // that works ahead looks at its one candidate only: outside the box = rejected)
             bool have = false;
             for (; j < k; ++j) {
-                const i64 elem = (i64)MM_STREAM_LOAD(&nn[i * k + j]);
+                const i64 elem = (i64)nn[i * k + j];
                 const bool valid_elem = !(nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem);
                 bool outside = true;
                 if (valid_elem) {
