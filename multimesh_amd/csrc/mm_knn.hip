@@ -179,9 +179,20 @@ __device__ __forceinline__ int count_and_rank(int c, bool live, int *__restrict_
     return base + (lane - head_lane);
 }
 
+// the cell of a point (the count and the scatter pass of a counting sort both call this: same arithmetic, same cell)
+__device__ __forceinline__ int cell_of_point(double x, double y, double z, const GridParams &g)
+{
+    const int cx = cell_coord(x, g.lox, g.ihx, g.nx);
+    const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
+    const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
+    return (cx * g.ny + cy) * g.nz + cz;
+}
+
 // With `list` the items are the points list[0 .. *list_count) (a density level's share of the targets).
+// rank_of[item] = the item's rank inside its cell; the scatter pass works the cell out again from the coordinates it
+// reads anyway (4 bytes per item written here and read there instead of 8: both passes move bytes, nothing else).
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
-                                                            GridParams g, int2 *__restrict__ cell_of,
+                                                            GridParams g, int *__restrict__ rank_of,
                                                             int *__restrict__ counts, const int *__restrict__ list,
                                                             const int *__restrict__ list_count)
 {
@@ -190,16 +201,10 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__rest
     int c = -1;
     if (live) {
         const i64 p = list ? (i64)list[e] : e;
-        const double x = src[p * ndim];
-        const double y = ndim > 1 ? src[p * ndim + 1] : 0.0;
-        const double z = ndim > 2 ? src[p * ndim + 2] : 0.0;
-        const int cx = cell_coord(x, g.lox, g.ihx, g.nx);
-        const int cy = cell_coord(y, g.loy, g.ihy, g.ny);
-        const int cz = cell_coord(z, g.loz, g.ihz, g.nz);
-        c = (cx * g.ny + cy) * g.nz + cz;
+        c = cell_of_point(src[p * ndim], ndim > 1 ? src[p * ndim + 1] : 0.0, ndim > 2 ? src[p * ndim + 2] : 0.0, g);
     }
     const int rank = count_and_rank(c, live, counts);
-    if (live) cell_of[e] = make_int2(c, rank);
+    if (live) rank_of[e] = rank;
 }
 
 // ---- exclusive scan of the per-cell counts (three small kernels) --------------------
@@ -337,16 +342,15 @@ __device__ __forceinline__ void store_record(double *__restrict__ rec, double x,
 __device__ __forceinline__ int record_id(double w) { return (int)__double_as_longlong(w); }
 
 __global__ __launch_bounds__(kBlock) void cell_scatter_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
-                                                              const int2 *__restrict__ cell_of,
+                                                              GridParams g, const int *__restrict__ rank_of,
                                                               const int *__restrict__ start,
                                                               double *__restrict__ sorted_rec)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nsrc) return;
-    const int2 cr = cell_of[e];
-    const i64 pos = (i64)start[cr.x] + cr.y;
-    store_record(sorted_rec + pos * kRec, src[e * ndim], ndim > 1 ? src[e * ndim + 1] : 0.0,
-                 ndim > 2 ? src[e * ndim + 2] : 0.0, (int)e);
+    const double x = src[e * ndim], y = ndim > 1 ? src[e * ndim + 1] : 0.0, z = ndim > 2 ? src[e * ndim + 2] : 0.0;
+    const i64 pos = (i64)start[cell_of_point(x, y, z, g)] + rank_of[e];
+    store_record(sorted_rec + pos * kRec, x, y, z, (int)e);
 }
 
 // ---- query --------------------------------------------------------------------------
@@ -2462,8 +2466,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 }
 
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
-__global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__restrict__ cell_of, i64 npts,
-                                                                const double *__restrict__ pts, int ndim,
+__global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int *__restrict__ rank_of, i64 npts,
+                                                                const double *__restrict__ pts, int ndim, GridParams g,
                                                                 const int *__restrict__ start,
                                                                 double *__restrict__ tsorted,
                                                                 const int *__restrict__ list,
@@ -2471,11 +2475,10 @@ __global__ __launch_bounds__(kBlock) void target_scatter_kernel(const int2 *__re
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (list ? (i64)*list_count : npts)) return;
-    const int2 cr = cell_of[t];
-    const i64 pos = (i64)start[cr.x] + cr.y;
     const i64 p = list ? (i64)list[t] : t;   // the record carries the target's own index
-    store_record(tsorted + pos * kRec, pts[p * ndim], ndim > 1 ? pts[p * ndim + 1] : 0.0,
-                 ndim > 2 ? pts[p * ndim + 2] : 0.0, (int)p);
+    const double x = pts[p * ndim], y = ndim > 1 ? pts[p * ndim + 1] : 0.0, z = ndim > 2 ? pts[p * ndim + 2] : 0.0;
+    const i64 pos = (i64)start[cell_of_point(x, y, z, g)] + rank_of[t];
+    store_record(tsorted + pos * kRec, x, y, z, (int)p);
 }
 
 // scratch of the lane kernel's work-item prepass (knn_query_typed carves it)
@@ -2796,12 +2799,12 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         }
     }
     const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
-    size_t need = mm_round256((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int2)) +    // cell_of {cell, rank}
+    size_t need = mm_round256((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int)) +     // rank of every source in its cell
                   mm_round256((size_t)(ncells + 1) * sizeof(int)) +              // counts
                   mm_round256((size_t)ntiles * sizeof(int)) + 4096;
     int rc = mm_scratch_begin(ctx, need);
     if (rc != MM_OK) { free_index(ix); return rc; }
-    int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int2));
+    int *cell_of = (int *)mm_scratch_take(ctx, (size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));   // rank of every source in its cell
     int *counts = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
     int *tile_sums = (int *)mm_scratch_take(ctx, (size_t)ntiles * sizeof(int));
     if (!cell_of || !counts || !tile_sums) {
@@ -2848,7 +2851,7 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                        ix->cell_start);
     if (nsrc > 0)
-        hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, cell_of,
+        hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            ix->cell_start, ix->sorted_xyz);
     e = hipGetLastError();
     if (e != hipSuccess) {
@@ -3052,7 +3055,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     for (const mm_knn_index *l = ix; l; l = l->fine) {
         const i64 nc = l->ncells;
         const int nt = (int)((nc + kScanTile - 1) / kScanTile);
-        need += mm_round256((size_t)npts * sizeof(int2)) +              // cell_of {cell, rank}
+        need += mm_round256((size_t)npts * sizeof(int)) +               // rank of every target in its cell
                 (l->fine ? mm_round256((size_t)npts * sizeof(int)) : 0) +   // targets passed down
                 ((l != ix || list0) ? mm_round256((size_t)npts * sizeof(unsigned)) : 0) +   // strips that hold targets
                 mm_round256((size_t)npts * kRec * sizeof(double)) +     // cell-sorted target records
@@ -3132,7 +3135,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         const GridParams gl = params_of(l);
         const i64 ncells = l->ncells;
         const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
-        int2 *cell_of = (int2 *)mm_scratch_take(ctx, (size_t)npts * sizeof(int2));
+        int *cell_of = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));   // rank of every target in its cell
         int *down_list = l->fine ? (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int)) : nullptr;
         int *counts = level == 0 ? counts0 : (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
         int *start = (int *)mm_scratch_take(ctx, (size_t)(ncells + 1) * sizeof(int));
@@ -3162,7 +3165,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                            (unsigned long long *)nullptr, 0);
         hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
-        hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim,
+        hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim, gl,
                            start, tsorted, list, list_count);
 #define MM_FAST(KK)                                                                                                  \
     launch_fast<KK, IDX>(ctx, l, gl, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count, down_list, \
