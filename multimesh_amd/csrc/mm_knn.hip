@@ -207,6 +207,49 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const double *__rest
     if (live) rank_of[e] = rank;
 }
 
+// The same count for many items over FEW cells (the unique GLL points of a target mesh over the coarse grid of a few
+// source elements: cfg5 has 7.2 M targets in 10,648 cells, and in the lexicographic order np.unique leaves them in every
+// wave in flight adds to the same few dozen counters: 0.6 ms where the 10 M targets of the metric take 0.08 -- merging
+// the single-cell waves of a workgroup before the add changes nothing, the contention is between workgroups).  Here a
+// workgroup takes a long contiguous share of the items, counts it in an LDS histogram of the whole grid, adds every
+// non-empty bin to the global counter ONCE -- the bin then holds the share's base in that cell -- and walks its share a
+// second time to hand out the ranks from the bins.  Two reads of the coordinates instead of one, a few hundred global
+// adds per workgroup instead of tens of thousands.
+constexpr int kHistBlock = 1024;
+constexpr int kHistCells = 16384;   // bins: 64 KB of LDS
+__global__ __launch_bounds__(kHistBlock) void cell_count_hist_kernel(const double *__restrict__ src, i64 nsrc, int ndim,
+                                                                     GridParams g, int ncells, int *__restrict__ rank_of,
+                                                                     int *__restrict__ counts)
+{
+    __shared__ int s_bin[kHistCells];
+    for (int t = threadIdx.x; t < ncells; t += kHistBlock) s_bin[t] = 0;
+    __syncthreads();
+    // this workgroup's share: whole chunks of kHistBlock items
+    const i64 chunks = (nsrc + kHistBlock - 1) / kHistBlock;
+    const i64 c_lo = chunks * blockIdx.x / gridDim.x, c_hi = chunks * (blockIdx.x + 1) / gridDim.x;
+    for (i64 ch = c_lo; ch < c_hi; ++ch) {
+        const i64 e = ch * kHistBlock + threadIdx.x;
+        const bool live = e < nsrc;
+        int c = -1;
+        if (live) c = cell_of_point(src[e * ndim], ndim > 1 ? src[e * ndim + 1] : 0.0, ndim > 2 ? src[e * ndim + 2] : 0.0, g);
+        (void)count_and_rank(c, live, s_bin);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ncells; t += kHistBlock) {
+        const int n = s_bin[t];
+        if (n > 0) s_bin[t] = atomicAdd(&counts[t], n);
+    }
+    __syncthreads();
+    for (i64 ch = c_lo; ch < c_hi; ++ch) {
+        const i64 e = ch * kHistBlock + threadIdx.x;
+        const bool live = e < nsrc;
+        int c = -1;
+        if (live) c = cell_of_point(src[e * ndim], ndim > 1 ? src[e * ndim + 1] : 0.0, ndim > 2 ? src[e * ndim + 2] : 0.0, g);
+        const int rank = count_and_rank(c, live, s_bin);   // (the bin holds base + ranks handed out so far)
+        if (live) rank_of[e] = rank;
+    }
+}
+
 // ---- exclusive scan of the per-cell counts (three small kernels) --------------------
 constexpr int kScanItems = 4;                       // items per thread
 constexpr int kScanTile = kBlock * kScanItems;      // items per block
@@ -3159,8 +3202,12 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         }
         if (!(level == 0 && one_fill))
             if (mm_zero_async(ctx, counts, mm_fill_span((size_t)(ncells + 1) * sizeof(int))) != MM_OK) return MM_ERR_HIP;
-        hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
-                           counts, list, list_count);
+        if (!list && ncells <= kHistCells && npts >= 64 * ncells)   // many targets over few cells (see the kernel)
+            hipLaunchKernelGGL(cell_count_hist_kernel, dim3(256), dim3(kHistBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl,
+                               (int)ncells, cell_of, counts);
+        else
+            hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
+                               counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                            (unsigned long long *)nullptr, 0);
         hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);

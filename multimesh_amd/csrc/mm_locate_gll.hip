@@ -23,6 +23,7 @@
 #include <math.h>
 
 #include "mm_common.h"
+#include "mm_newton_hex8.h"
 
 namespace {
 
@@ -85,6 +86,12 @@ __device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double
     }
 }
 
+#ifndef MM_GLL_GUESS_TRIPS   // (tuning builds only: the oracle's start runs 8)
+#define MM_GLL_GUESS_TRIPS 8
+#endif
+constexpr int kGllGuessTrips = MM_GLL_GUESS_TRIPS;   // hex8 trips of the corner solve that starts a 3-D inverse transform
+constexpr double kGllGuessMax = 3.0;    // a start beyond this (or NaN) is not used
+
 template <int ORDER, int DIM>
 struct Gll {
     static constexpr int n = ORDER + 1;
@@ -99,6 +106,29 @@ struct Gll {
         gll_nodes<ORDER>(g);
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xi[d] = 0.0;
+        if (DIM == 3 && ORDER >= 2) {
+            // Start from the solution of the element's eight CORNERS' trilinear map (the hex8 Newton of
+            // mm_newton_hex8.h, at most kGllGuessTrips trips of ~300 fp64 instructions against ~1.2 k for one step
+            // here): a straight-sided element -- its nodes the trilinear images of the GLL points -- is then left
+            // after one or two steps instead of five, a curved one after three.  Same arithmetic as the oracle's start
+            // (mmo_gll_inverse_transform; the hex8 solve is bit-identical in both: tests/test_newton_host.py).  A start
+            // that is not finite or far outside is not used.
+            double cx[8], cy[8], cz[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int node = (MM_R(c) > 0 ? n - 1 : 0) + n * ((MM_S(c) > 0 ? n - 1 : 0) + n * (MM_T(c) > 0 ? n - 1 : 0));
+                cx[c] = ctrl[3 * node + 0];
+                cy[c] = ctrl[3 * node + 1];
+                cz[c] = ctrl[3 * node + 2];
+            }
+            double q[3];
+            (void)newton_hex8(pnt[0], pnt[1], pnt[DIM - 1], cx, cy, cz, q, kGllGuessTrips);
+            if (fabs(q[0]) <= kGllGuessMax && fabs(q[1]) <= kGllGuessMax && fabs(q[2]) <= kGllGuessMax) {
+                xi[0] = q[0];
+                xi[1] = q[1];
+                xi[DIM - 1] = q[2];
+            }
+        }
         for (int it = 0; it < 25; ++it) {
             double l[DIM][n], dl[DIM][n];
 #pragma unroll

@@ -115,8 +115,16 @@ static void hex8_inverse_jacobian(const double xi[3], const double vtx[8][3],
 /* update is xi += (J^-1)^T * residual (:295-300).                     */
 /* Returns 1 when converged, 0 otherwise; *iters = residual tests done.*/
 /* ------------------------------------------------------------------ */
+static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap);
+
 int mmo_hex8_newton(const double pnt[3], const double vtx[8][3], double xi[3],
                     int *iters)
+{
+    return hex8_newton_capped(pnt, vtx, xi, iters, 50);
+}
+
+/* cap: the reference's 50 (:264); the GLL section starts its own iteration from a few trips of this one. */
+static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap)
 {
     xi[0] = xi[1] = xi[2] = 0;
     const double sx = fabs(vtx[1][0] - vtx[0][0]);
@@ -126,7 +134,7 @@ int mmo_hex8_newton(const double pnt[3], const double vtx[8][3], double xi[3],
     const double scale = sz > sxy ? sz : sxy;
     const double tol = 1e-8 * scale;
     double col[8];
-    for (int it = 0; it < 50; ++it) {
+    for (int it = 0; it < cap; ++it) {
         double res[3];
         for (int a = 0; a < 3; ++a) {
             for (int n = 0; n < 8; ++n) col[n] = vtx[n][a];
@@ -145,7 +153,7 @@ int mmo_hex8_newton(const double pnt[3], const double vtx[8][3], double xi[3],
             xi[a] = xi[a] + acc;
         }
     }
-    if (iters) *iters = 50;
+    if (iters) *iters = cap;
     return 0;
 }
 
@@ -523,6 +531,20 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
     const int n = order + 1;
     gll_nodes(order, g);
     for (int d = 0; d < dim; ++d) xi[d] = 0.0;
+    if (dim == 3 && order >= 2) {
+        /* Start from the solution of the eight CORNERS' trilinear map: at most 8 trips of the hex8 iteration above
+         * (corner c of trilinearinterpolator.c:8-10 is the control node at the matching end of every axis).  A start
+         * that is not finite or lies beyond 3 is not used.  Part of this path's definition, like the fma order
+         * below: the HIP kernel does the same. */
+        double vtx[8][3], q[3];
+        for (int c = 0; c < 8; ++c) {
+            const int node = (kR[c] > 0 ? n - 1 : 0) + n * ((kS[c] > 0 ? n - 1 : 0) + n * (kT[c] > 0 ? n - 1 : 0));
+            for (int a = 0; a < 3; ++a) vtx[c][a] = ctrl[3 * node + a];
+        }
+        (void)hex8_newton_capped(pnt, (const double(*)[3])vtx, q, NULL, 8);
+        if (fabs(q[0]) <= 3.0 && fabs(q[1]) <= 3.0 && fabs(q[2]) <= 3.0)
+            for (int d = 0; d < 3; ++d) xi[d] = q[d];
+    }
     for (int it = 0; it < 25; ++it) {
         for (int d = 0; d < dim; ++d) lagrange_1d(order, g, xi[d], l[d], dl[d]);
         double x[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};

@@ -595,6 +595,19 @@ def test_knn_many_targets_per_cell_multi_round(ctx):
     assert np.array_equal(ctx.knn_build(src).query(q, 20).numpy(), O.knn_ckdtree(src, q, 20, workers=-1)[0])
 
 
+@pytest.mark.parametrize("order_by", ["random", "lexicographic"])
+def test_knn_many_targets_over_few_cells_histogram_count(ctx, order_by):
+    # >= 64 targets per cell of a grid of <= 16,384 cells: the targets' counting sort counts through an LDS histogram
+    # per workgroup (cell_count_hist_kernel); lexicographic order (what np.unique leaves) is the contended case
+    rng = np.random.default_rng(12)
+    src = rng.uniform(size=(4_000, 3))
+    q = rng.uniform(-0.02, 1.02, size=(300_000, 3))
+    if order_by == "lexicographic":
+        q = q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))]
+    for k in (8, 20):
+        assert np.array_equal(ctx.knn_build(src).query(q, k).numpy(), O.knn_ckdtree(src, q, k, workers=-1)[0])
+
+
 @pytest.mark.parametrize("k", [8, 20])
 def test_knn_strips_shared_between_waves(ctx, k):
     # ~1,400 targets per strip of two cells (the unique GLL points of a fine mesh over the centroids of a
