@@ -385,7 +385,10 @@ void mmo_knn_brute(const double *src, i64 nsrc, const double *pts, i64 npts,
 /*    (order 1: -1,1; order 2: -1,0,1; order 4: -1,-sqrt(3/7),0,       */
 /*    sqrt(3/7),1), node index p = i + (n+1) j + (n+1)^2 k with xi_1   */
 /*    fastest;                                                         */
-/*  - Newton from xi = 0 on x(xi) = sum_p L_p(xi) X_p, Jacobian by the */
+/*  - Newton on x(xi) = sum_p L_p(xi) X_p from xi = 0 -- in 3-D at     */
+/*    order >= 2 from the solution of the eight corners' trilinear map */
+/*    (<= 8 trips of the hex8 iteration of section A6, used when       */
+/*    finite and within |xi| <= 3) --, Jacobian by the                 */
 /*    analytic basis derivatives, cofactor solve; converged when the   */
 /*    largest component of the update is < 1e-10; at most 25 updates;  */
 /*    NaN when the Jacobian is singular, an iterate leaves [-10,10]    */
