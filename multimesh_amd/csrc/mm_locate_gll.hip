@@ -86,6 +86,13 @@ __device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double
     }
 }
 
+// Waves per SIMD the register allocator must leave room for in the GLL locate kernels.  1: it takes what the kernel
+// needs -- at order 4 in 3-D 256 VGPRs + ~90 AGPRs, one wave per SIMD, nothing in scratch memory -- and the lower orders
+// still run 2 to 5 waves (95 - 211 VGPRs).  Asking for 3 (168 VGPRs, rounds 1 - 2) left 340 registers of the order-4
+// kernels in scratch: cfg5's locate stage 6.2 ms at 3, 5.5 at 2 (150 spilled), 5.1 at 1.
+#ifndef MM_GLL_WAVES
+#define MM_GLL_WAVES 1
+#endif
 #ifndef MM_GLL_GUESS_TRIPS   // (tuning builds only: the oracle's start runs 8)
 #define MM_GLL_GUESS_TRIPS 8
 #endif
@@ -354,7 +361,7 @@ constexpr int kGllLazyK = 8;   // candidates asked of the kNN stage up front by 
 constexpr int kGllWalkFrom = 3; // passes that advance one candidate before the lanes walk their lists
 
 template <int ORDER, int DIM, typename IDX>
-__global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
+__global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
                                                              const IDX *__restrict__ nn,
                                                              const double *__restrict__ gll_points, i64 nelem,
                                                              const double *__restrict__ points, double tolerance,
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(64, 3) void locate_gll_pass_kernel(i64 k, int kavai
 // wave with more distinct elements (thinly populated elements) takes further turns of the stage/solve
 // loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
 template <int ORDER, int DIM, typename IDX>
-__global__ __launch_bounds__(64, 3) void locate_gll_first_pass_kernel(
+__global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_first_pass_kernel(
     i64 k, int kavail, i64 npoints, const IDX *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
     const double *__restrict__ points, double tolerance, int snap_to_nearest, GllEmit em,
     unsigned long long *__restrict__ nmissing, const int *__restrict__ order,
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(256) void gll_box_kernel(i64 nelem, const double *_
 // One lane per target, candidates in order (lock-step: this variant is the completeness path, the
 // tolerance/snap variant above is the tuned one).
 template <int ORDER, int DIM>
-__global__ __launch_bounds__(64, 3) void locate_gll_v1_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
+__global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_v1_kernel(i64 k, i64 npoints, const i64 *__restrict__ nn,
                                                               const double *__restrict__ gll_points, i64 nelem,
                                                               const double *__restrict__ boxes,
                                                               const double *__restrict__ points,
