@@ -86,6 +86,13 @@ __device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double
     }
 }
 
+// The node loads of the unrolled sum-factorised loops are kept from being hoisted to the top (all (order+1)^3 x 3
+// values live at once: spills) by a compiler fence every MM_GLL_FENCE_EVERY rows of nodes (cfg5's locate stage, ms:
+// every row 5.04, every 2nd 4.92, every 3rd / 5th 5.06 / 5.03, none: 470 registers spilled).
+#ifndef MM_GLL_FENCE_EVERY
+#define MM_GLL_FENCE_EVERY 2
+#endif
+#define MM_GLL_ROW_FENCE(row) do { if ((row) % MM_GLL_FENCE_EVERY == 0) asm volatile("" ::: "memory"); } while (0)
 // Waves per SIMD the register allocator must leave room for in the GLL locate kernels.  1: it takes what the kernel
 // needs -- at order 4 in 3-D 256 VGPRs + ~90 AGPRs, one wave per SIMD, nothing in scratch memory -- and the lower orders
 // still run 2 to 5 waves (95 - 211 VGPRs).  Asking for 3 (168 VGPRs, rounds 1 - 2) left 340 registers of the order-4
@@ -161,7 +168,7 @@ struct Gll {
                     for (int j = 0; j < n; ++j) {
                         // keep the scheduler from hoisting all (order+1)^3 node loads to the top of
                         // the unrolled loop: one row of nodes at a time
-                        asm volatile("" ::: "memory");
+                        MM_GLL_ROW_FENCE(j);
                         double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                         for (int i = 0; i < n; ++i) {
@@ -292,7 +299,7 @@ struct Gll {
             for (int j = 0; j < n; ++j) {
                 // one row of field values at a time (see inverse_transform): hoisting all P loads
                 // to the top of the unrolled loop spills
-                asm volatile("" ::: "memory");
+                MM_GLL_ROW_FENCE(j);
 #pragma unroll
                 for (int i = 0; i < n; ++i) {
                     const int p = i + n * (j + n * k);
