@@ -35,6 +35,11 @@ constexpr int kBlock = 256;
 constexpr int kScanTileItems = 1024;  // items per block of mm_exclusive_scan_int
 constexpr int kWave = 64;
 constexpr int kBins = 256;            // 8 bits a pass
+// The main sort of mm_unique_points orders the rows by the top 64 - kKeyLowBits bits of x's sortable image (sign, exponent,
+// 36 bits of mantissa: six passes instead of eight); rows that agree in those bits form a "run" whatever the rest of x says,
+// and the runs are put in full (x, y, z, index) order afterwards -- as the runs of bit-equal x (shared nodes) always were.
+// Two different x within 1.5e-11 of each other (relative) merely share a run.
+constexpr int kKeyLowBits = 16;
 constexpr int kSortWaves = 4;
 constexpr int kSortBlock = kSortWaves * kWave;
 constexpr int kItems = 16;            // keys per thread: batches of 64 consecutive keys per wave
@@ -198,9 +203,11 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const u64 *__
 // Runs of bit-equal keys in the sorted order: the thread at a run's head puts its rows in (y, z, index)
 // order (insertion sort on the row indices; runs of shared-node copies are 2 to 8 long); a run longer than
 // kMaxRun is only reported.
+// (from the x coordinate on: the main sort orders by the TOP bits of x only -- kKeyLowBits below -- so two rows of a run
+// may differ in the rest of x)
 __device__ __forceinline__ bool row_before(const double *__restrict__ pts, int dim, unsigned a, unsigned b)
 {
-    for (int c = 1; c < dim; ++c) {
+    for (int c = 0; c < dim; ++c) {
         const u64 ka = sortable(pts[(i64)a * dim + c]), kb = sortable(pts[(i64)b * dim + c]);
         if (ka != kb) return ka < kb;
     }
@@ -212,10 +219,10 @@ __global__ __launch_bounds__(kBlock) void run_fixup_kernel(const u64 *__restrict
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || j + 1 >= n) return;
-    const u64 kj = key[j];
-    if ((j > 0 && key[j - 1] == kj) || key[j + 1] != kj) return;   // not the head of a run of two or more
+    const u64 kj = key[j] >> kKeyLowBits;
+    if ((j > 0 && (key[j - 1] >> kKeyLowBits) == kj) || (key[j + 1] >> kKeyLowBits) != kj) return;   // not the head of a run of two or more
     int len = 2;
-    while (j + len < n && len <= kMaxRun && key[j + len] == kj) ++len;
+    while (j + len < n && len <= kMaxRun && (key[j + len] >> kKeyLowBits) == kj) ++len;
     if (len > kMaxRun) {
         // (a face of an axis-aligned box mesh: thousands of rows share x) its start goes on a list; the run is
         // sorted with the other long ones afterwards
@@ -244,11 +251,11 @@ __global__ __launch_bounds__(kBlock) void run_length_kernel(const u64 *__restric
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nruns) return;
     const i64 s0 = start[r];
-    const u64 k = key[s0];
-    i64 lo = s0, hi = n;   // key[lo] == k, key[hi] > k (or hi == n)
+    const u64 k = key[s0] >> kKeyLowBits;
+    i64 lo = s0, hi = n;   // key[lo] == k, key[hi] > k (or hi == n), by the bits the main sort ordered
     while (hi - lo > 1) {
         const i64 mid = (lo + hi) >> 1;
-        if (key[mid] == k) lo = mid; else hi = mid;
+        if ((key[mid] >> kKeyLowBits) == k) lo = mid; else hi = mid;
     }
     len[r] = (int)(hi - s0);
 }
@@ -344,9 +351,10 @@ extern "C" int64_t mm_unique_points(mm_context *ctx, const double *points_d, int
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     // stable sort of (ka, va)[0 .. cnt) by the keys' 64 bits with (kb, vb) as the other buffer; eight passes, so the
     // result is back in (ka, va)
-    auto radix_sort = [&](u64 *ka, u64 *kb, unsigned *va, unsigned *vb, i64 cnt) -> int {
+    // (first_shift: bits below it are not sorted by; the number of passes stays even)
+    auto radix_sort = [&](u64 *ka, u64 *kb, unsigned *va, unsigned *vb, i64 cnt, int first_shift) -> int {
         const int tiles = (int)((cnt + kTile - 1) / kTile);
-        for (int shift = 0; shift < 64; shift += 8) {
+        for (int shift = first_shift; shift < 64; shift += 8) {
             hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)tiles), dim3(kSortBlock), 0, ctx->stream, ka, cnt, shift, tiles,
                                counts);
             int src = mm_exclusive_scan_int(ctx, counts, (i64)kBins * tiles, offsets, count_sums);
@@ -368,7 +376,7 @@ extern "C" int64_t mm_unique_points(mm_context *ctx, const double *points_d, int
         const dim3 g((unsigned)((cnt + kBlock - 1) / kBlock));
         for (int comp = (int)dim - 1; comp >= 0; --comp) {
             hipLaunchKernelGGL(key_kernel, g, block, 0, ctx->stream, points_d, cnt, (int)dim, comp, va, ka);
-            int src = radix_sort(ka, kb, va, vb, cnt);
+            int src = radix_sort(ka, kb, va, vb, cnt, 0);
             if (src != MM_OK) return src;
         }
         return MM_OK;
@@ -379,7 +387,9 @@ extern "C" int64_t mm_unique_points(mm_context *ctx, const double *points_d, int
     if (!general) {
         hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, ord_a, n);
         hipLaunchKernelGGL(key_kernel, grid, block, 0, ctx->stream, points_d, n, (int)dim, 0, ord_a, key_a);
-        if ((rc = radix_sort(key_a, key_b, ord_a, ord_b, n)) != MM_OK) return rc;
+        static_assert(kKeyLowBits % 16 == 0, "an even number of 8-bit passes");
+        // (1-D: nothing follows that could order the rest of x -- all 64 bits)
+        if ((rc = radix_sort(key_a, key_b, ord_a, ord_b, n, dim > 1 ? kKeyLowBits : 0)) != MM_OK) return rc;
         if (dim > 1) {
             MM_HIP_CHECK(hipMemsetAsync(long_runs, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(run_fixup_kernel, grid, block, 0, ctx->stream, key_a, n, points_d, (int)dim, ord_a, long_runs);

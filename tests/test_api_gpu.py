@@ -163,7 +163,8 @@ def test_unique_points_equal_numpy(dim):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["general", "box_faces", "many_long_runs", "lattice"])
+@pytest.mark.parametrize("kind", ["general", "box_faces", "many_long_runs", "lattice", "x_differs_in_the_last_bits",
+                                  "a_plane_with_noise_in_x"])
 def test_unique_points_runs_of_equal_x(kind):
     # one sort by x, then the runs of equal x: short ones (copies of shared nodes) in place, the few long ones (the
     # faces of a box mesh) as a sub-sort, clouds that are mostly long runs by dim stable sorts -- every route against np.unique
@@ -179,6 +180,14 @@ def test_unique_points_runs_of_equal_x(kind):
     elif kind == "many_long_runs":
         pts[:, 0] = np.round(pts[:, 0] * 5000) / 5000       # 5001 values of x, ~30 rows each: some runs longer than the limit
         pts[:60_000, 0] = np.round(pts[:60_000, 0] * 400) / 400   # ... and 401 values with 150 rows each
+    elif kind == "x_differs_in_the_last_bits":
+        # the main sort orders by the top 48 bits of x: rows whose x agree in those and differ below form runs that the
+        # fix-up has to put in full (x, y, z) order -- short ones, and one longer than the in-place limit
+        base = np.round(pts[:, 0] * 3000) / 3000 + 0.25
+        pts[:, 0] = base * (1.0 + rng.integers(0, 200, size=n) * 2.0 ** -52)
+        pts[:500, 0] = 0.625 * (1.0 + rng.integers(0, 4000, size=500) * 2.0 ** -52)
+    elif kind == "a_plane_with_noise_in_x":
+        pts[:, 0] = 3.0 * (1.0 + rng.integers(0, 1 << 15, size=n) * 2.0 ** -52)     # ONE run: the dim-sorts route
     elif kind == "lattice":
         g = np.arange(53, dtype=np.float64) / 52
         pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)[rng.permutation(53 ** 3)]

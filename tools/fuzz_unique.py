@@ -11,7 +11,7 @@ t0 = time.time()
 for case in range(ncases):
     dim = int(rng.integers(1, 4))
     n = int(rng.choice([rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 1_500_000)]))
-    kind = rng.choice(["floats", "few_values", "lattice", "signed"])
+    kind = rng.choice(["floats", "few_values", "lattice", "signed", "last_bits"])
     if kind == "floats":
         base = rng.normal(size=(max(1, n // int(rng.integers(1, 6))), dim))
         pts = base[rng.integers(0, len(base), size=n)]
@@ -19,6 +19,12 @@ for case in range(ncases):
         pts = rng.integers(-3, 4, size=(n, dim)).astype(np.float64)
     elif kind == "lattice":
         pts = np.round(rng.uniform(-5, 5, size=(n, dim)), int(rng.integers(0, 3)))
+    elif kind == "last_bits":
+        # few values of x, each spread over its last bits (the main sort orders by the top 48 bits of x only)
+        pts = rng.uniform(-2, 2, size=(n, dim))
+        vals = rng.uniform(-2, 2, size=int(rng.integers(1, 40)))
+        pts[:, 0] = vals[rng.integers(0, len(vals), size=n)] * (1.0 + rng.integers(0, int(rng.choice([2, 50, 70000])), size=n) * 2.0 ** -52)
+        pts = pts[rng.integers(0, n, size=n)]
     else:
         pts = rng.integers(-2, 3, size=(n, dim)).astype(np.float64) * rng.choice([1.0, -0.0, 1e-300, 1e300], size=(n, dim))
     pts = np.ascontiguousarray(pts)
