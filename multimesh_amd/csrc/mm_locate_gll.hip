@@ -123,7 +123,7 @@ struct Gll {
         if (DIM == 3 && ORDER >= 2) {
             // Start from the solution of the element's eight CORNERS' trilinear map (the hex8 Newton of
             // mm_newton_hex8.h, at most kGllGuessTrips trips of ~300 fp64 instructions against ~1.2 k for one step
-            // here): a straight-sided element -- its nodes the trilinear images of the GLL points -- is then left
+            // here, the converged trip's update applied as well): a straight-sided element -- its nodes the trilinear images of the GLL points -- is then left
             // after one or two steps instead of five, a curved one after three.  Same arithmetic as the oracle's start
             // (mmo_gll_inverse_transform; the hex8 solve is bit-identical in both: tests/test_newton_host.py).  A start
             // that is not finite or far outside is not used.
@@ -136,7 +136,7 @@ struct Gll {
                 cz[c] = ctrl[3 * node + 2];
             }
             double q[3];
-            (void)newton_hex8(pnt[0], pnt[1], pnt[DIM - 1], cx, cy, cz, q, kGllGuessTrips);
+            (void)newton_hex8<true>(pnt[0], pnt[1], pnt[DIM - 1], cx, cy, cz, q, kGllGuessTrips);
             if (fabs(q[0]) <= kGllGuessMax && fabs(q[1]) <= kGllGuessMax && fabs(q[2]) <= kGllGuessMax) {
                 xi[0] = q[0];
                 xi[1] = q[1];

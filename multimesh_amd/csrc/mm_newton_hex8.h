@@ -96,6 +96,11 @@ MM_HD void newton_update(const double (&M)[3][3], double r0, double r1, double r
 // axis.  Returns true when converged; xi receives the last iterate either way.
 // first_it > 0 CONTINUES a solve: xi holds the iterate after first_it updates (the iteration is a deterministic map
 // of the iterate, so running trips [0, a) and later [a, b) gives the iterates of [0, b)); trips first_it .. max_it - 1.
+// POLISH (the GLL path's start, mm_locate_gll.hip): the trip that finds the residual converged still applies its update
+// before it returns -- one more hex8 trip (~300 instructions) that takes the iterate from the reference's 1e-8 of an
+// element to rounding, which saves a step of the 125-node map (~1.2 k) behind it.  The hex8 path never polishes: its
+// iterates are the reference's.
+template <bool POLISH = false>
 MM_HD bool newton_hex8(const double px, const double py, const double pz, const double (&x)[8],
                        const double (&y)[8], const double (&z)[8], double (&xi)[3], const int max_it = 50,
                        const int first_it = 0)
@@ -116,7 +121,8 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
         const double r0 = px - map_axis_centre(x);
         const double r1 = py - map_axis_centre(y);
         const double r2 = pz - map_axis_centre(z);
-        if (__builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol) return true;  // z is never tested (reference quirk)
+        const bool done0 = __builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol;  // z is never tested (reference quirk)
+        if (done0 && !POLISH) return true;
         double M[3][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -138,6 +144,7 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
             M[2][2] = MM_T(n) > 0 ? M[2][2] + z[n] : M[2][2] - z[n];
         }
         newton_update(M, r0, r1, r2, xi);
+        if (POLISH && done0) return true;
         it = 1;
     }
     for (; it < max_it; ++it) {
@@ -148,7 +155,8 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
         const double r0 = px - map_axis(x, fr[1], fs[1], ft[1]);
         const double r1 = py - map_axis(y, fr[1], fs[1], ft[1]);
         const double r2 = pz - map_axis(z, fr[1], fs[1], ft[1]);
-        if (__builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol) return true;  // z is never tested (reference quirk)
+        const bool done = __builtin_fabs(r0) < tol && __builtin_fabs(r1) < tol;  // z is never tested (reference quirk)
+        if (done && !POLISH) return true;
         // ... and their pairwise products: dN_n/dxi_0 = 0.125 R_n fs ft is an exact scaling of fl(fs ft), the same for
         // the other two
         double gst[2][2], grt[2][2], grs[2][2];
@@ -182,6 +190,7 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
             M[2][2] = it_ ? M[2][2] + d2 * z[n] : M[2][2] - d2 * z[n];
         }
         newton_update(M, r0, r1, r2, xi);
+        if (POLISH && done) return true;
     }
     return false;
 }

@@ -115,16 +115,23 @@ static void hex8_inverse_jacobian(const double xi[3], const double vtx[8][3],
 /* update is xi += (J^-1)^T * residual (:295-300).                     */
 /* Returns 1 when converged, 0 otherwise; *iters = residual tests done.*/
 /* ------------------------------------------------------------------ */
-static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap);
+static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap, int polish);
 
 int mmo_hex8_newton(const double pnt[3], const double vtx[8][3], double xi[3],
                     int *iters)
 {
-    return hex8_newton_capped(pnt, vtx, xi, iters, 50);
+    return hex8_newton_capped(pnt, vtx, xi, iters, 50, 0);
 }
 
-/* cap: the reference's 50 (:264); the GLL section starts its own iteration from a few trips of this one. */
-static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap)
+/* The corner solve the GLL section starts from (test hook: tests/test_newton_host.py compares it with the kernels'). */
+int mmo_hex8_newton_start(const double pnt[3], const double vtx[8][3], double xi[3], int cap)
+{
+    return hex8_newton_capped(pnt, vtx, xi, NULL, cap, 1);
+}
+
+/* cap: the reference's 50 (:264); the GLL section starts its own iteration from a few trips of this one, with
+ * polish != 0: the trip that finds the residual converged still applies its update before it returns. */
+static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap, int polish)
 {
     xi[0] = xi[1] = xi[2] = 0;
     const double sx = fabs(vtx[1][0] - vtx[0][0]);
@@ -140,17 +147,24 @@ static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], doubl
             for (int n = 0; n < 8; ++n) col[n] = vtx[n][a];
             res[a] = pnt[a] - hex8_map_axis(col, xi[0], xi[1], xi[2]);
         }
-        if (fabs(res[0]) < tol && fabs(res[1]) < tol && fabs(res[0]) < tol) {
+        const int done = fabs(res[0]) < tol && fabs(res[1]) < tol && fabs(res[0]) < tol;
+        if (done && !polish) {
             if (iters) *iters = it + 1;
             return 1;
         }
         double inv[3][3];
         hex8_inverse_jacobian(xi, vtx, inv);
+        double upd[3];
         for (int a = 0; a < 3; ++a) {
             /* row a of the transposed inverse = column a of inv */
             double acc = 0;
             for (int j = 0; j < 3; ++j) acc = acc + inv[j][a] * res[j];
-            xi[a] = xi[a] + acc;
+            upd[a] = acc;
+        }
+        for (int a = 0; a < 3; ++a) xi[a] = xi[a] + upd[a];
+        if (done) {
+            if (iters) *iters = it + 1;
+            return 1;
         }
     }
     if (iters) *iters = cap;
@@ -535,8 +549,8 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
     gll_nodes(order, g);
     for (int d = 0; d < dim; ++d) xi[d] = 0.0;
     if (dim == 3 && order >= 2) {
-        /* Start from the solution of the eight CORNERS' trilinear map: at most 8 trips of the hex8 iteration above
-         * (corner c of trilinearinterpolator.c:8-10 is the control node at the matching end of every axis).  A start
+        /* Start from the solution of the eight CORNERS' trilinear map: at most 8 trips of the hex8 iteration above,
+         * the converged trip's update applied as well (corner c of trilinearinterpolator.c:8-10 is the control node at the matching end of every axis).  A start
          * that is not finite or lies beyond 3 is not used.  Part of this path's definition, like the fma order
          * below: the HIP kernel does the same. */
         double vtx[8][3], q[3];
@@ -544,7 +558,7 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
             const int node = (kR[c] > 0 ? n - 1 : 0) + n * ((kS[c] > 0 ? n - 1 : 0) + n * (kT[c] > 0 ? n - 1 : 0));
             for (int a = 0; a < 3; ++a) vtx[c][a] = ctrl[3 * node + a];
         }
-        (void)hex8_newton_capped(pnt, (const double(*)[3])vtx, q, NULL, 8);
+        (void)hex8_newton_capped(pnt, (const double(*)[3])vtx, q, NULL, 8, 1);
         if (fabs(q[0]) <= 3.0 && fabs(q[1]) <= 3.0 && fabs(q[2]) <= 3.0)
             for (int d = 0; d < 3; ++d) xi[d] = q[d];
     }

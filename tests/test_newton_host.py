@@ -97,6 +97,35 @@ def test_final_iterates_equal_the_compiled_reference(host):
         assert bad == 0, (case, first)
 
 
+def test_the_gll_paths_corner_solve_equals_the_oracles(host):
+    # mm_locate_gll.hip starts a 3-D inverse transform from newton_hex8<POLISH = true> (at most 8 trips, the converged
+    # trip's update applied as well); the oracle from mmo_hex8_newton_start: the same iterate, bit for bit
+    L = O.lib()
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags=["C_CONTIGUOUS"])
+    host.nh_compare_start.restype = C.c_int64
+    host.nh_compare_start.argtypes = [C.c_int64, f64p, f64p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+    fn = C.cast(L.mmo_hex8_newton_start, C.c_void_p)
+    for case, (jitter, scale, offset, spread) in enumerate(CASES):
+        rng = np.random.default_rng(700 + case)
+        pnt, vtx = elements(rng, 100_000, jitter, scale, offset, spread)
+        for cap in (8, 3, 1):
+            first = C.c_int64()
+            bad = host.nh_compare_start(len(pnt), pnt, vtx, fn, cap, C.byref(first))
+            assert bad == 0, (case, cap, first.value)
+    # and the polish does what it is for: on a straight-sided element the start is the solution to rounding
+    rng = np.random.default_rng(1)
+    pnt, vtx = elements(rng, 2000, 0.3, 1.0, (0, 0, 0), 0.5)
+    host.nh_start.restype = C.c_int
+    host.nh_start.argtypes = [f64p, f64p, f64p, C.c_int]
+    worst = 0.0
+    for p, v in zip(pnt, vtx):
+        xi = np.zeros(3)
+        if host.nh_start(p, np.ascontiguousarray(v), xi, 8) and np.abs(xi).max() < 1.2:
+            r = 0.125 * ((1 + RST[:, 0] * xi[0]) * (1 + RST[:, 1] * xi[1]) * (1 + RST[:, 2] * xi[2])) @ v - p
+            worst = max(worst, np.abs(r).max())
+    assert worst < 1e-13
+
+
 def test_degenerate_inputs_give_the_same_verdicts(host):
     # flat element (zero determinant), a point exactly at the centre, a point exactly on a corner, zero-size element
     L = O.lib()
