@@ -348,6 +348,36 @@ __global__ __launch_bounds__(kBlock) void scan_tile_offsets_kernel(int *__restri
     }
 }
 
+// scan_apply_kernel for few tiles, straight behind scan_tile_sums_kernel: the workgroup sums the tiles before its own
+// itself (tile_sums are the RAW sums here)
+constexpr int kScanSelfTiles = 2048;
+__global__ __launch_bounds__(kBlock) void scan_apply_self_kernel(const int *__restrict__ counts, i64 n,
+                                                                 const int *__restrict__ tile_sums,
+                                                                 int *__restrict__ start,
+                                                                 const long long *__restrict__ mirror_src,
+                                                                 long long *__restrict__ mirror_dst, int mirror_n)
+{
+    if (mirror_src && blockIdx.x == 0 && (int)threadIdx.x < mirror_n) mirror_dst[threadIdx.x] = mirror_src[threadIdx.x];
+    int before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += kBlock) before += tile_sums[t];
+    int tile_base;
+    (void)block_exclusive_scan(before, &tile_base);
+    const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = base + i < n ? counts[base + i] : 0;
+        s += v[i];
+    }
+    int total;
+    int excl = block_exclusive_scan(s, &total) + tile_base;
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) start[base + i] = excl;
+        excl += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) start[n] = excl;   // the total number of items
+}
+
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int *__restrict__ counts, i64 n,
                                                             const int *__restrict__ tile_offsets,
                                                             int *__restrict__ start)
@@ -2734,13 +2764,29 @@ void free_index(mm_knn_index *ix)
 
 // Exclusive prefix sum of n ints on the context's stream: start[0..n] (start[n] = total).
 // tile_sums: scratch of ceil(n / 1024) ints.  Shared with the GLL locate's target ordering.
+// The scan behind scan_tile_sums_kernel: with few tiles every workgroup of the last kernel adds up the sums of the tiles
+// before its own by itself (at most kScanSelfTiles values, L2-resident) and the single-workgroup kernel in between -- a
+// dispatch of 5 us, thirty times per mm_unique_points -- is not launched; with many tiles the three-kernel form.
+// mirror_*: see scan_tile_offsets_kernel.
+static void launch_scan_tail(mm_context *ctx, const int *counts, i64 n, int *tile_sums, int ntiles, int *start,
+                             const long long *mirror_src = nullptr, long long *mirror_dst = nullptr, int mirror_n = 0)
+{
+    if (ntiles <= kScanSelfTiles) {
+        hipLaunchKernelGGL(scan_apply_self_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, (const int *)tile_sums,
+                           start, mirror_src, mirror_dst, mirror_n);
+    } else {
+        hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles, mirror_src,
+                           mirror_dst, mirror_n);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, (const int *)tile_sums, start);
+    }
+}
+
 int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums)
 {
     const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums,
                        (unsigned long long *)nullptr, 0);
-    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, n, tile_sums, start);
+    launch_scan_tail(ctx, counts, n, tile_sums, ntiles, start);
     MM_HIP_CHECK(hipGetLastError());
     return MM_OK;
 }
@@ -2880,9 +2926,9 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
                            want_stat ? (unsigned long long *)stat : (unsigned long long *)nullptr, sample_shift);
     // (the scan's second kernel writes the statistic to the pinned mirror on its way; the host waits for it -- ev_misc --
     // only after the rest of the build is queued, or not at all: mm_knn_build_guessed)
-    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles,
-                       want_stat ? (const long long *)stat : (const long long *)nullptr,
-                       (long long *)(ctx->h_counters + kStatSlot), want_stat ? kMaxLevels : 0);
+    launch_scan_tail(ctx, counts, ncells, tile_sums, ntiles, ix->cell_start,
+                     want_stat ? (const long long *)stat : (const long long *)nullptr,
+                     (long long *)(ctx->h_counters + kStatSlot), want_stat ? kMaxLevels : 0);
     if (want_stat) {
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_misc, ctx->stream);
         if (e != hipSuccess) {
@@ -2891,8 +2937,6 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
             return MM_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
-                       ix->cell_start);
     if (nsrc > 0)
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            ix->cell_start, ix->sorted_xyz);
@@ -3210,8 +3254,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
                                counts, list, list_count);
         hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
                            (unsigned long long *)nullptr, 0);
-        hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, tile_sums, ntiles);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums, start);
+        launch_scan_tail(ctx, counts, ncells, tile_sums, ntiles, start);
         hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim, gl,
                            start, tsorted, list, list_count);
 #define MM_FAST(KK)                                                                                                  \
