@@ -229,6 +229,26 @@ int64_t mm_interpolate_hex8_host(mm_context *ctx, const double *nodes_h, int64_t
  * so every output is bit-identical to the eager evaluation; on = 0 forces the eager one. */
 int mm_set_lazy_lists(mm_context *ctx, int on);
 
+/* Floating-point mode of the hex8 locate stage (mm_locate_hex8, mm_interpolate_hex8*, triLinearInterpolator).
+ *   MM_FP_EXACT (default): the reference's arithmetic operation for operation (src/trilinearinterpolator.c:150-375)
+ *     -- node ids, weights and interpolated values bit-identical to the reference.
+ *   MM_FP_TOL: the Newton inversion runs in a cheaper arithmetic (polynomial form of the map, fused multiply-adds,
+ *     Cramer's rule; csrc/mm_newton_hex8.h) that must CERTIFY every decision the reference makes -- each residual test
+ *     against 1e-8 * scale, the final max|xi| against 1.025 -- with a margin two orders above the rounding differences
+ *     between the two arithmetics; a solve it cannot certify is repeated in the reference's arithmetic.  Element / node
+ *     ids and the failed count stay bit-identical; weights and values agree with the reference to
+ *     max(1e-12, 64 eps |x| / h) (|x| / h: coordinate magnitude over element size; 1e-12 on the BASELINE meshes),
+ *     relative to max|weight| = 1 resp. max|field|.
+ * The environment variable MM_FP_MODE=tol makes MM_FP_TOL the default of new contexts (how a user of the legacy
+ * symbols opts in). */
+#define MM_FP_EXACT 0
+#define MM_FP_TOL 1
+int mm_set_fp_mode(mm_context *ctx, int mode);
+int mm_get_fp_mode(mm_context *ctx);
+/* out4 = {solves of the last hex8 locate stage that MM_FP_TOL repeated in the reference's arithmetic, targets that went
+ * through the reference-order kernel, targets of a long on-demand list's second pass, 0}.  Synchronises. */
+int mm_last_locate_stats(mm_context *ctx, long long *out4);
+
 /* Stage timers (hipEvents on the context's stream).  With profiling on, every kernel
  * launched by the calls above is bracketed by events; mm_last_timings fills ms[stage] for
  * the stages of the LAST call (0 for stages that did not run) and returns the stage count. */

@@ -87,6 +87,7 @@ struct mm_context {
     // stage timers
     int profiling = 0;
     int lazy_lists = 1;   // mm_set_lazy_lists
+    int fp_mode = 0;      // mm_set_fp_mode (MM_FP_EXACT; MM_FP_MODE=tol in the environment starts contexts in MM_FP_TOL)
     hipEvent_t ev_begin[MM_STAGE_COUNT];
     hipEvent_t ev_end[MM_STAGE_COUNT];
     bool ev_used[MM_STAGE_COUNT];

@@ -143,6 +143,10 @@ extern "C" int mm_context_create(int device, void *hip_stream, mm_context **out)
     }
     ctx->device = device;
     ctx->stream = (hipStream_t)hip_stream;
+    {
+        const char *fp = getenv("MM_FP_MODE");
+        if (fp && (fp[0] == 't' || fp[0] == 'T' || fp[0] == '1')) ctx->fp_mode = MM_FP_TOL;
+    }
     hipError_t e = mm_raw_alloc(device, (void **)&ctx->d_counters, 64 * sizeof(i64));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 64 * sizeof(i64));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(i64), 0);
@@ -379,6 +383,36 @@ extern "C" int mm_set_lazy_lists(mm_context *ctx, int on)
 {
     MM_REQUIRE(ctx != nullptr, "ctx is null");
     ctx->lazy_lists = on ? 1 : 0;
+    return MM_OK;
+}
+
+extern "C" int mm_set_fp_mode(mm_context *ctx, int mode)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(mode == MM_FP_EXACT || mode == MM_FP_TOL, "mode must be MM_FP_EXACT or MM_FP_TOL");
+    ctx->fp_mode = mode;
+    return MM_OK;
+}
+
+extern "C" int mm_get_fp_mode(mm_context *ctx)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    return ctx->fp_mode;
+}
+
+// {solves of the last hex8 locate stage that MM_FP_TOL could not certify and repeated in the reference's arithmetic,
+//  targets that went through the reference-order kernel (fallback / failure candidates), 0, 0}.  Synchronises.
+extern "C" int mm_last_locate_stats(mm_context *ctx, long long *out4)
+{
+    MM_REQUIRE(ctx != nullptr && out4 != nullptr, "null argument");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    int h[16];
+    MM_HIP_CHECK(hipMemcpyAsync(h, reinterpret_cast<const int *>(ctx->d_counters + 8), sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out4[0] = h[13];
+    out4[1] = h[15];
+    out4[2] = h[14];
+    out4[3] = 0;
     return MM_OK;
 }
 

@@ -132,7 +132,8 @@ struct Emit {
     double *out;            // [npoints][ncomp]
 };
 
-template <typename ID>
+// FMA (MM_FP_TOL only): the sum as one chain of fused multiply-adds -- within a few ulp of NumPy's order.
+template <bool FMA = false, typename ID>
 __device__ __forceinline__ void emit_row(const Emit &em, i64 i, const ID (&id)[8], const double (&wt)[8])
 {
     if (em.enc) {
@@ -151,6 +152,16 @@ __device__ __forceinline__ void emit_row(const Emit &em, i64 i, const ID (&id)[8
             sid[n] = (unsigned long long)(i64)id[n] < (unsigned long long)em.nnodes ? (i64)id[n] : 0;
         for (int c = 0; c < em.ncomp; ++c) {
             const double *f = em.fields + (i64)c * em.nnodes;
+            if (FMA) {
+                double v[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) v[n] = f[sid[n]];
+                double acc = 0.0;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc = __builtin_fma(v[n], wt[n], acc);
+                em.out[i * em.ncomp + c] = acc;
+                continue;
+            }
             double p[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) p[n] = f[sid[n]] * wt[n];
@@ -267,6 +278,9 @@ constexpr int kPassBlock = 256;
 #ifndef MM_PASS_WAVES   // tuning builds only: minimum waves per SIMD the register allocator must leave room for
 #define MM_PASS_WAVES 2
 #endif
+#ifndef MM_FAST_WAVES   // ... for the MM_FP_TOL instances
+#define MM_FAST_WAVES 2
+#endif
 // LDS entries per wave and queue.  A full queue (>= 64 waiting) is served before anything is added to it, the
 // slowest tier first: tiers 1 and 2 only grow in rounds of the tier below, which run while they hold fewer
 // than 64 (< 128 after the round); tier 0 grows in every round -- 63 + 64 from its own rounds, then one
@@ -323,8 +337,15 @@ __device__ unsigned long long g_loc_stamps[kLocStampSlots * 8];
 // (points, rows, queues), the target's own index (outputs, reference-order list) comes out of its record.
 // NID: the type node ids are held in across a solve -- int when the caller knows the mesh has fewer than 2^31 nodes
 // (the fused pipeline does), i64 as the connectivity array stores them otherwise.
-template <bool EXODUS, typename IDX, bool SORTED, typename NID>
-__global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(i64 k, i64 npoints,
+// FAST (MM_FP_TOL, mm_set_fp_mode): tier 0's solves are newton_hex8_fast under tier 0's cap -- a quarter of the
+// instructions, the reference's verdict or "unsure" (mm_newton_hex8.h).  An unsure solve waits, same candidate, in the
+// wave's tier-1 queue like a slow one and is solved again there FROM xi = 0 IN THE REFERENCE'S ARITHMETIC (cap kMidIters,
+// then tier 2 as ever); what the exact tiers accept leaves with the reference's weights, bit for bit.  (First version:
+// a global redo list and a second launch of the exact kernel over it -- 0.35 ms for 1.3 % of the solves: a wave's few
+// rounds of 50-trip stragglers and the candidates behind them, one after the other with nothing to overlap them.  Inside
+// the one launch they ride along.)  unsure_count (nullable): solves repeated, one atomic per wave at its end.
+template <bool EXODUS, typename IDX, bool SORTED, typename NID, bool FAST = false>
+__global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) void locate_pass_kernel(i64 k, i64 npoints,
                                                                  const IDX *__restrict__ nn,
                                                                  const i64 *__restrict__ conn, i64 nelem,
                                                                  Emit em,
@@ -334,13 +355,15 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                                                                  int *__restrict__ slow_count,
                                                                  const int *__restrict__ in_list,
                                                                  const int *__restrict__ in_count, int j0,
-                                                                 int planes = 0, int panel = 0)
+                                                                 int planes = 0, int panel = 0,
+                                                                 int *__restrict__ unsure_count = nullptr)
 {
-    // in_list (nullable, not with SORTED): only the targets in_list[0 .. *in_count), each from candidate j0 on -- the second
+    // in_list (nullable): only the targets in_list[0 .. *in_count), each from candidate j0 on -- the second
     // pass over the targets that exhausted their lazily evaluated candidates, on their full lists (nn then holds k = the
     // full length per row; candidates before j0 were rejected by the first pass and would be rejected again).
     if (in_list) npoints = (i64)*in_count;
     // [wave][tier][entry]: tier 0 ordinary retries, 1 solves that outlasted kPassIters, 2 ... kMidIters
+    // (FAST: tier 1 holds the unsure solves as well, which start again from xi = 0: its iterate queue is not used)
     __shared__ int2 s_queue0[kPassBlock / 64][kWaveQueue0];
     __shared__ int2 s_queue12[kPassBlock / 64][2][kWaveQueue];
     __shared__ double s_qxi[kPassBlock / 64][2][3][kWaveQueue];   // ... and the iterate their solve stopped at
@@ -350,6 +373,7 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
     int2 *const my_q2 = s_queue12[threadIdx.x >> 6][1];
     double (*const my_xi1)[kWaveQueue] = s_qxi[threadIdx.x >> 6][0];
     double (*const my_xi2)[kWaveQueue] = s_qxi[threadIdx.x >> 6][1];
+    int unsure = 0;   // (FAST; wave-uniform) solves handed to the exact tiers
     int held0 = 0, held1 = 0, held2 = 0;   // wave-uniform: entries waiting in each tier's queue
 
     // XCD-aware deal of the fresh batches.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
@@ -446,9 +470,15 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
         } else if (next < total) {
             const i64 q = next + lane;
             active = q < total;
-            if (active) i = in_list ? (i64)in_list[q] : q;
             j = j0;
+            if (active) {
+                i = in_list ? (i64)in_list[q] : q;
+            }
             advance();
+#ifdef MM_EXP_NODRAIN   // timing experiment only (results are wrong): how long the drain at the end of the pass takes
+        } else if (true) {
+            break;
+#endif
         } else if (held0 > 0) {
             // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
             // handful of short rounds at the very end of the pass instead of another pass).  The idle
@@ -559,10 +589,20 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             MM_LCOUNT(2, have && j < k);
             if (j >= k) {
                 outcome = 3;  // no candidate left that could be accepted: fallback / failure is the reference's call
+            } else if (FAST && tier == 0 && have) {
+                double xi[3];
+                const int verdict = newton_hex8_fast(px, py, pz, c.x, c.y, c.z, xi, kPassIters);
+                if (verdict == MM_FAST_ACCEPT) {
+                    weights_hex8_fast(xi, wt);
+                    outcome = 1;
+                } else if (verdict == MM_FAST_UNSURE) {
+                    outcome = 2;
+                }
             } else if (have) {
                 double xi[3] = {xi_in[0], xi_in[1], xi_in[2]};
-                // (a tier's solves start where the tier below's cap stopped them: trips [first, cap))
-                const int first = tier == 0 ? 0 : (tier == 1 ? kPassIters : kMidIters);
+                // (a tier's solves start where the tier below's cap stopped them: trips [first, cap); FAST: tier 1 repeats
+                // tier 0's fast solve in the reference's arithmetic, from the start)
+                const int first = tier == 0 ? 0 : (tier == 1 ? (FAST ? 0 : kPassIters) : kMidIters);
                 const bool converged = newton_hex8(px, py, pz, c.x, c.y, c.z, xi, cap, first);
                 xi_in[0] = xi[0];
                 xi_in[1] = xi[1];
@@ -594,7 +634,10 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
             const int first = mine ? __ffsll((long long)mine) - 1 : G;
             const int g = lane - group_base;
             if (active && g == first) {
-                if (outcome == 1) emit_row(em, tid, c.id, wt);
+                if (outcome == 1) {
+                    if (FAST && tier == 0) emit_row<true>(em, tid, c.id, wt);
+                    else emit_row<false>(em, tid, c.id, wt);
+                }
                 else if (outcome == 2) slower = true;
                 else slow_list[atomicAdd(slow_count, 1)] = (int)tid;
             } else if (active && first == G && g == 0) {
@@ -626,12 +669,14 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
                 qx[1][at] = xi_in[1];
                 qx[2][at] = xi_in[2];
             }
+            if (FAST && tier == 0) unsure += __popcll(svote);
             if (up == 1) held1 += __popcll(svote);
             else held2 += __popcll(svote);
         }
         wave_fence();
         MM_LSTAMP(6);   // queue appends
     }
+    if (FAST && unsure_count && lane == 0 && unsure > 0) atomicAdd(unsure_count, unsure);
 #ifdef MM_LOCATE_STAMPS
     if (lane == 0) {
         unsigned long long *slot = g_loc_stamps + (size_t)((blockIdx.x * (kPassBlock / 64) + (threadIdx.x >> 6)) & (kLocStampSlots - 1)) * 8;
@@ -643,6 +688,37 @@ __global__ __launch_bounds__(kPassBlock, MM_PASS_WAVES) void locate_pass_kernel(
 
 }  // namespace
 
+// The instance of the pass kernel for a launch (all instances share one signature).
+template <typename IDX>
+struct PassFn {
+    typedef void (*type)(i64, i64, const IDX *, const i64 *, i64, Emit, const double *, const double *, int *, int *,
+                         const int *, const int *, int, int, int, int *);
+};
+
+template <typename IDX, bool FAST>
+static typename PassFn<IDX>::type pass_kernel_for(bool exodus, bool sorted, bool nid32)
+{
+#define MM_PASS_PICK(EX, SO) (nid32 ? locate_pass_kernel<EX, IDX, SO, int, FAST> : locate_pass_kernel<EX, IDX, SO, i64, FAST>)
+    if (sorted) return exodus ? MM_PASS_PICK(true, true) : MM_PASS_PICK(false, true);
+    return exodus ? MM_PASS_PICK(true, false) : MM_PASS_PICK(false, false);
+#undef MM_PASS_PICK
+}
+
+// workgroups of `fn` the device keeps resident (the pass kernel is launched with exactly that many)
+template <typename FN>
+static i64 resident_workgroups(mm_context *ctx, FN fn)
+{
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPassBlock, 0);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    if (e != hipSuccess || per_cu < 1 || cus < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+        cus = 256;
+    }
+    return (i64)per_cu * cus;
+}
+
 // Launch the whole locate stage on ctx->stream (no synchronisation).  Scratch: the long queue,
 // the reference-order list and their counters come from the context's scratch pool, so this must be the only
 // scratch user between mm_scratch_begin calls of the caller -- it calls mm_scratch_begin itself.
@@ -652,7 +728,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                                i64 *d_nfailed, int zero_failed, const mm_lazy_lists *lazy, const double *tsorted)
 {
     // the failed-point counter and the stage's own 16 counters ([15] length of the reference-order list, [14] of the
-    // second pass's) sit in one block of the context's counter array (mm_common.h): ONE fill clears both
+    // second pass's, [13] the solves MM_FP_TOL repeated exactly) sit in one block of the context's counter array (mm_common.h): ONE
+    // fill clears both
     int *counters = reinterpret_cast<int *>(ctx->d_counters + 8);
     if (d_nfailed == ctx->d_counters) {
         if (mm_zero_async(ctx, ctx->d_counters, 16 * sizeof(i64)) != MM_OK) return MM_ERR_HIP;
@@ -664,26 +741,24 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     MM_REQUIRE(npoints < (i64)0x7fffffff, "too many targets for one launch");
     const int block = 256;
     const i64 full_grid = (npoints + block - 1) / block;
+    const bool fast = ctx->fp_mode == MM_FP_TOL;
 
     // (a buffer of its own, not the scratch pool: a long list's on-demand neighbour query carves the pool anew)
     char *slow_block = nullptr;
-    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, 2 * mm_round256((size_t)npoints * sizeof(int)), (void **)&slow_block);
+    const size_t list_bytes = mm_round256((size_t)npoints * sizeof(int));
+    int rc = mm_buffer_get(ctx, MM_BUF_LOC_SLOW, 2 * list_bytes, (void **)&slow_block);
     if (rc != MM_OK) return rc;
     int *slow = (int *)slow_block;
-    int *slow2 = (int *)(slow_block + mm_round256((size_t)npoints * sizeof(int)));
+    int *slow2 = (int *)(slow_block + list_bytes);
     int *slow_count = counters + 15;
-    i64 resident = 0;
-    {
-        int per_cu = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, locate_pass_kernel<true, IDX, true, int>, kPassBlock, 0);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        if (e != hipSuccess || per_cu < 1 || cus < 1) {
-            (void)hipGetLastError();
-            per_cu = 2;
-            cus = 256;
-        }
-        resident = (i64)per_cu * cus;
-    }
+    int *unsure_count = counters + 13;
+    // (node ids in 32 bits when the caller has told us how many nodes there are: fewer registers across the solve)
+    const bool nid32 = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
+    // (tsorted: rows nn[] and the records are in the kNN stage's cell-sorted order; the reference-order kernel
+    // below works on the targets' own indices either way)
+    const typename PassFn<IDX>::type first_fn = fast ? pass_kernel_for<IDX, true>(conn_is_exodus != 0, tsorted != nullptr, nid32)
+                                                     : pass_kernel_for<IDX, false>(conn_is_exodus != 0, tsorted != nullptr, nid32);
+    const i64 resident = resident_workgroups(ctx, first_fn);
     const i64 grid = resident < full_grid ? resident : full_grid;
     // ONE launch over all targets.  Persistent waves: exactly as many workgroups as the device keeps
     // resident, so that every wave lives for the whole pass and its private queues see a long stream
@@ -691,31 +766,12 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     mm_stage_begin(ctx, MM_STAGE_LOCATE_PASS0);
     {
         dim3 g_((unsigned)grid), b_(block);
-        // (tsorted: rows nn[] and the records are in the kNN stage's cell-sorted order; the reference-order kernel
-        // below works on the targets' own indices either way)
-        // (node ids in 32 bits when the caller has told us how many nodes there are: fewer registers across the solve)
-        const bool nid32 = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
         // (walk order of the sorted targets: see the kernel; the kNN grid's x dimension comes with the lazy lists)
         static const int panel_env = getenv("MM_LOCATE_PANEL") ? atoi(getenv("MM_LOCATE_PANEL")) : kPassPanel;
         const int planes = (tsorted && lazy && lazy->index && !lazy->index->fine) ? lazy->index->dims[0] : 0;
         const int panel = panel_env;   // (0: in order, < 0: the kernel's default)
-#define MM_PASS_LAUNCH(EX, SO, NID, P)                                                                                  \
-    hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, SO, NID>), g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, \
-                       nodes, P, slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel)
-        if (tsorted && conn_is_exodus) {
-            if (nid32) MM_PASS_LAUNCH(true, true, int, tsorted);
-            else MM_PASS_LAUNCH(true, true, i64, tsorted);
-        } else if (tsorted) {
-            if (nid32) MM_PASS_LAUNCH(false, true, int, tsorted);
-            else MM_PASS_LAUNCH(false, true, i64, tsorted);
-        } else if (conn_is_exodus) {
-            if (nid32) MM_PASS_LAUNCH(true, false, int, pts);
-            else MM_PASS_LAUNCH(true, false, i64, pts);
-        } else {
-            if (nid32) MM_PASS_LAUNCH(false, false, int, pts);
-            else MM_PASS_LAUNCH(false, false, i64, pts);
-        }
-#undef MM_PASS_LAUNCH
+        hipLaunchKernelGGL(first_fn, g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, nodes, tsorted ? tsorted : pts,
+                           slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel, unsure_count);
     }
     mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     // out of candidates without an acceptance: reference-order kernel
@@ -748,17 +804,10 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                 if (g2 > resident) g2 = resident;
                 dim3 g_((unsigned)g2), b_(block);
                 const bool nid32b = em.nnodes > 0 && em.nnodes < (i64)0x7fffffff;
-#define MM_PASS2_LAUNCH(EX, NID)                                                                                          \
-    hipLaunchKernelGGL((locate_pass_kernel<EX, IDX, false, NID>), g_, b_, 0, ctx->stream, k_slow, npoints, nn_slow, conn,   \
-                       nelem, em, nodes, pts, slow2, slow2_count, (const int *)slow, (const int *)slow_count, (int)k)
-                if (conn_is_exodus) {
-                    if (nid32b) MM_PASS2_LAUNCH(true, int);
-                    else MM_PASS2_LAUNCH(true, i64);
-                } else {
-                    if (nid32b) MM_PASS2_LAUNCH(false, int);
-                    else MM_PASS2_LAUNCH(false, i64);
-                }
-#undef MM_PASS2_LAUNCH
+                hipLaunchKernelGGL((fast ? pass_kernel_for<IDX, true>(conn_is_exodus != 0, false, nid32b)
+                                         : pass_kernel_for<IDX, false>(conn_is_exodus != 0, false, nid32b)),
+                                   g_, b_, 0, ctx->stream, k_slow, npoints, nn_slow, conn, nelem, em, nodes, pts, slow2, slow2_count,
+                                   (const int *)slow, (const int *)slow_count, (int)k, 0, 0, unsure_count);
                 slow = slow2;
                 slow_count = slow2_count;
             }

@@ -194,3 +194,205 @@ MM_HD bool newton_hex8(const double px, const double py, const double pz, const 
     }
     return false;
 }
+
+// =====================================================================================================================
+// MM_FP_TOL (mm_set_fp_mode): the same DECISIONS as the iteration above from a quarter of its instructions.
+//
+// The reference's operation order costs ~300 fp64 instructions per trip.  north_star asks for element indices bit-exact
+// and fields "within a stated relative tolerance", so a second solve is allowed to round differently as long as it
+// reaches the reference's verdict -- converged or not, max|xi| on which side of 1.025 -- with certainty, and says so
+// when it cannot.  newton_hex8_fast:
+//   * writes the trilinear map as the polynomial c0 + r cR + s cS + t cT + rs cRS + rt cRT + st cST + rst cRST (the
+//     coefficients, carried at 8x, are a Walsh-Hadamard butterfly of the corners: 24 additions per axis and solve),
+//     so that one trip's residual AND Jacobian are 11 fused multiply-adds per axis (at xi = 0 they are c0 and
+//     cR / cS / cT themselves), and solves the 3x3 system by cross products (Cramer) with a refined reciprocal:
+//     ~85 instructions per trip;
+//   * follows the reference's control flow (start at 0, residual test on x and y only, update, cap);
+//   * returns MM_FAST_ACCEPT / MM_FAST_REJECT only when every test the reference makes on the way has MARGIN:
+//       - the two iterations start from the same point and differ by rounding alone, which one update turns into at
+//         most E ~ eps * |coordinates| * |J^-1| in xi (a few 1e-13 on the metric meshes).  Newton's map has the
+//         derivative -J^-1 DJ u: where the updates u shrink at least two-fold per trip it is a contraction and the
+//         difference stays at the level of E trip after trip; that is checked (trip i >= 1: 2 |u_i| <= |u_i-1|);
+//       - every residual test must then fall outside tol -+ rho and the final max|xi| outside 1.025 -+ delta, with
+//         delta = 256 eps |v| |J^-1| and rho = 64 eps |v| + |J| delta taken from the element at xi = 0 -- two to
+//         three orders above the differences measured (tests/test_newton_host.py runs millions of solves against
+//         the reference iteration and reports the largest difference in units of delta);
+//     anything else -- a test inside its band, updates that do not shrink, no convergence inside the cap, a
+//     non-finite number, an element so ill-conditioned that delta > 1e-6 -- returns MM_FAST_UNSURE and the caller
+//     repeats the solve with newton_hex8 (locate_pass_kernel<..., FAST> hands such targets to the exact kernel).
+// With MM_FAST_ACCEPT xi is the reference's final iterate to within delta (same trip count).
+// =====================================================================================================================
+#define MM_FAST_REJECT 0
+#define MM_FAST_ACCEPT 1
+#define MM_FAST_UNSURE 2
+
+constexpr double kFastEps = 2.220446049250313e-16;
+constexpr double kFastCxi = 256.0;     // delta = kFastCxi * eps * |v|_8 * |(8J)^-1|
+constexpr double kFastCres = 64.0;     // rho_8 = kFastCres * eps * |v|_8 + 3 |8J|_max * delta
+constexpr double kFastDeltaMax = 1e-6; // elements worse conditioned than this are not certified at all
+
+// 1 / d to about 2^-26 (what v_rcp_f64 delivers; the host build cuts an exact quotient down to that, so that the
+// host tests exercise the refinement below rather than a better seed than the device has)
+MM_HD double mm_rcp_seed(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(d);
+#else
+    double y = 1.0 / d;
+    unsigned long long b;
+    __builtin_memcpy(&b, &y, 8);
+    b &= ~((1ull << 26) - 1ull);
+    __builtin_memcpy(&y, &b, 8);
+    return y;
+#endif
+}
+
+MM_HD double mm_max3abs(double a, double b, double c)
+{
+    const double m = __builtin_fmax(__builtin_fabs(a), __builtin_fabs(b));
+    return __builtin_fmax(m, __builtin_fabs(c));
+}
+
+// 8 x the polynomial coefficients of one axis (corner signs MM_R / MM_S / MM_T): {c0, cR, cS, cT, cRS, cRT, cST, cRST}
+MM_HD void hex8_poly_axis(const double (&v)[8], double (&c)[8])
+{
+    // along r: corner pairs (0,3) (1,2) (4,5) (7,6); along s; along t
+    const double s_mm = v[0] + v[3], d_mm = v[3] - v[0];
+    const double s_pm = v[1] + v[2], d_pm = v[2] - v[1];
+    const double s_mp = v[4] + v[5], d_mp = v[5] - v[4];
+    const double s_pp = v[7] + v[6], d_pp = v[6] - v[7];
+    const double ss_m = s_mm + s_pm, sd_m = s_pm - s_mm;
+    const double ss_p = s_mp + s_pp, sd_p = s_pp - s_mp;
+    const double ds_m = d_mm + d_pm, dd_m = d_pm - d_mm;
+    const double ds_p = d_mp + d_pp, dd_p = d_pp - d_mp;
+    c[0] = ss_m + ss_p;
+    c[3] = ss_p - ss_m;
+    c[2] = sd_m + sd_p;
+    c[6] = sd_p - sd_m;
+    c[1] = ds_m + ds_p;
+    c[5] = ds_p - ds_m;
+    c[4] = dd_m + dd_p;
+    c[7] = dd_p - dd_m;
+}
+
+// Cramer's rule for sum_q a_q u_q = res (a_r, a_s, a_t: the rows of 8 J as vectors in x, y, z): the three cross products
+// nr = as x at, ns = at x ar, nt = ar x as and 1 / det, det = ar . nr; then u_q = (res . n_q) / det.
+MM_HD void fast_invert(const double (&ar)[3], const double (&as)[3], const double (&at)[3], double (&nr)[3],
+                       double (&ns)[3], double (&nt)[3], double &rdet)
+{
+#define MM_CROSS(o, a, b)                                      \
+    o[0] = __builtin_fma(a[1], b[2], -(a[2] * b[1]));          \
+    o[1] = __builtin_fma(a[2], b[0], -(a[0] * b[2]));          \
+    o[2] = __builtin_fma(a[0], b[1], -(a[1] * b[0]));
+    MM_CROSS(nr, as, at)
+    MM_CROSS(ns, at, ar)
+    MM_CROSS(nt, ar, as)
+#undef MM_CROSS
+    const double det = __builtin_fma(ar[2], nr[2], __builtin_fma(ar[1], nr[1], ar[0] * nr[0]));
+    double y = mm_rcp_seed(det);
+    y = __builtin_fma(y, __builtin_fma(-det, y, 1.0), y);
+    rdet = __builtin_fma(y, __builtin_fma(-det, y, 1.0), y);
+}
+
+MM_HD double fast_dot(const double (&a)[3], const double (&b)[3])
+{
+    return __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], a[0] * b[0]));
+}
+
+// one axis of the map at (r, s, t): its three gradients (8x) and 8 x the residual, 11 fused multiply-adds
+MM_HD void fast_axis(const double (&c)[8], double q0, double r, double s, double t, double &gr, double &gs, double &gt,
+                     double &res)
+{
+    const double A = __builtin_fma(t, c[7], c[4]);
+    const double D = __builtin_fma(t, c[6], c[2]);
+    gr = __builtin_fma(s, A, __builtin_fma(t, c[5], c[1]));
+    gs = __builtin_fma(r, A, D);
+    gt = __builtin_fma(s, __builtin_fma(r, c[7], c[6]), __builtin_fma(r, c[5], c[3]));
+    res = __builtin_fma(-t, c[3], __builtin_fma(-s, D, __builtin_fma(-r, gr, q0)));
+}
+
+// diag (nullable, host tests): {delta, the trip that found convergence, largest |u_i| / |u_i-1| seen}
+MM_HD int newton_hex8_fast(const double px, const double py, const double pz, const double (&x)[8],
+                           const double (&y)[8], const double (&z)[8], double (&xi)[3], const int max_it,
+                           double *diag = nullptr)
+{
+    // the reference's tolerance (trilinearinterpolator.c:278-282), at 8x like everything below
+    const double sx = __builtin_fabs(x[1] - x[0]);
+    const double sy = __builtin_fabs(y[1] - y[0]);
+    const double sz = __builtin_fabs(z[1] - z[0]);
+    const double tol8 = 8e-8 * __builtin_fmax(__builtin_fmax(sx, sy), sz);
+    double cx[8], cy[8], cz[8];
+    hex8_poly_axis(x, cx);
+    hex8_poly_axis(y, cy);
+    hex8_poly_axis(z, cz);
+    if (diag) diag[0] = diag[1] = diag[2] = 0.;
+    // Trip 0, at xi = 0: the rows of 8 J and 8 x the residual are the coefficients themselves.
+    double ar[3] = {cx[1], cy[1], cz[1]}, as[3] = {cx[2], cy[2], cz[2]}, at[3] = {cx[3], cy[3], cz[3]};
+    const double q0[3] = {__builtin_fma(8.0, px, -cx[0]), __builtin_fma(8.0, py, -cy[0]), __builtin_fma(8.0, pz, -cz[0])};
+    double res[3] = {q0[0], q0[1], q0[2]};
+    double nr[3], ns[3], nt[3], rdet;
+    fast_invert(ar, as, at, nr, ns, nt, rdet);
+    // the margins, from the element at its centre: |(8J)^-1| <= 3 max|cofactor| / |det| (row sums), |v|_8 = 8 x the
+    // largest coordinate around (corner sums, the point, the element's extent)
+    double cof = mm_max3abs(nr[0], nr[1], nr[2]);
+    cof = __builtin_fmax(cof, mm_max3abs(ns[0], ns[1], ns[2]));
+    cof = __builtin_fmax(cof, mm_max3abs(nt[0], nt[1], nt[2]));
+    double jmax = mm_max3abs(ar[0], ar[1], ar[2]);
+    jmax = __builtin_fmax(jmax, mm_max3abs(as[0], as[1], as[2]));
+    jmax = __builtin_fmax(jmax, mm_max3abs(at[0], at[1], at[2]));
+    const double v8 = __builtin_fma(4.0, jmax, __builtin_fmax(mm_max3abs(cx[0], cy[0], cz[0]), 8.0 * mm_max3abs(px, py, pz)));
+    const double delta = (kFastCxi * kFastEps) * v8 * (3.0 * cof * __builtin_fabs(rdet));
+    const double rho8 = __builtin_fma(3.0 * jmax, delta, (kFastCres * kFastEps) * v8);
+    const double lo8 = tol8 - rho8, hi8 = tol8 + rho8;
+    if (diag) diag[0] = delta;
+    // (one exit: the structuriser turns early returns from inside the loop into a web of register copies)
+    int verdict = MM_FAST_UNSURE;
+    double r = 0., s = 0., t = 0., m_prev = 0.;
+    int it = 0;
+    bool go = delta < kFastDeltaMax && lo8 > 0.;   // (a NaN gives false)
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    while (go) {
+        // the reference's stop test (x and y only), with its band
+        const double a0 = __builtin_fabs(res[0]), a1 = __builtin_fabs(res[1]);
+        if (a0 < lo8 && a1 < lo8) {
+            if (diag) diag[1] = it;
+            const double worst = mm_max3abs(r, s, t);
+            verdict = worst < (1 + 0.025) - delta ? MM_FAST_ACCEPT : (worst > (1 + 0.025) + delta ? MM_FAST_REJECT : MM_FAST_UNSURE);
+            break;
+        }
+        // inside the band (or not a number); or no verdict inside the cap: the reference may run to 50
+        if (!(a0 > hi8 || a1 > hi8) || it + 1 >= max_it) break;
+        if (it > 0) fast_invert(ar, as, at, nr, ns, nt, rdet);
+        const double dr = fast_dot(res, nr), ds = fast_dot(res, ns), dt = fast_dot(res, nt);
+        const double m = mm_max3abs(dr, ds, dt) * __builtin_fabs(rdet);   // |u|
+        if (diag && it > 0 && m_prev > 0. && m / m_prev > diag[2]) diag[2] = m / m_prev;
+        if (it > 0 && !(2.0 * m <= m_prev)) break;   // not (yet) contracting: roundings may grow
+        m_prev = m;
+        r = __builtin_fma(dr, rdet, r);
+        s = __builtin_fma(ds, rdet, s);
+        t = __builtin_fma(dt, rdet, t);
+        ++it;
+        fast_axis(cx, q0[0], r, s, t, ar[0], as[0], at[0], res[0]);
+        fast_axis(cy, q0[1], r, s, t, ar[1], as[1], at[1], res[1]);
+        fast_axis(cz, q0[2], r, s, t, ar[2], as[2], at[2], res[2]);
+    }
+    xi[0] = r;
+    xi[1] = s;
+    xi[2] = t;
+    return verdict;
+}
+
+// The eight weights in factored form, 0.125 (1 +- r)(1 +- s)(1 +- t) -- MM_FP_TOL only (the exact path keeps the
+// reference's expanded polynomials, trilinearinterpolator.c:174-197): within a few ulp of those.
+MM_HD void weights_hex8_fast(const double (&xi)[3], double (&w)[8])
+{
+    const double fr[2] = {__builtin_fma(-0.125, xi[0], 0.125), __builtin_fma(0.125, xi[0], 0.125)};
+    const double fs[2] = {1.0 - xi[1], 1.0 + xi[1]};
+    const double ft[2] = {1.0 - xi[2], 1.0 + xi[2]};
+    const double g[2][2] = {{fs[0] * ft[0], fs[0] * ft[1]}, {fs[1] * ft[0], fs[1] * ft[1]}};
+#define MM_W(n) w[n] = fr[MM_R(n) > 0] * g[MM_S(n) > 0][MM_T(n) > 0];
+    MM_W(0) MM_W(1) MM_W(2) MM_W(3) MM_W(4) MM_W(5) MM_W(6) MM_W(7)
+#undef MM_W
+}

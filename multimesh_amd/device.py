@@ -14,7 +14,7 @@ import ctypes as C
 
 import numpy as np
 
-from .helpers import MM_KNN_MAX_K, STAGES, MultiMeshHipError, check, load_lib
+from .helpers import MM_FP_EXACT, MM_FP_TOL, MM_KNN_MAX_K, STAGES, MultiMeshHipError, check, load_lib
 
 _NP2ITEM = {np.dtype(np.float64): 8, np.dtype(np.int64): 8, np.dtype(np.int32): 4, np.dtype(np.uint8): 1}
 
@@ -162,6 +162,23 @@ class Context:
         """interpolate_hex8 asks the kNN stage for the 8 nearest first and for the full list only for
         targets that exhaust them (bit-identical outputs; default on)."""
         check(self.lib.mm_set_lazy_lists(self.handle, 1 if on else 0), "mm_set_lazy_lists")
+
+    def set_fp_mode(self, mode):
+        """Arithmetic of the hex8 locate stage: "exact" (default: the reference's operations, every output bit-identical)
+        or "tol" (cheaper Newton arithmetic that certifies every decision of the reference's iteration or repeats the
+        solve exactly: node ids / failed count still bit-identical, weights and values to ~1e-12; include/multimesh_hip.h)."""
+        m = {"exact": MM_FP_EXACT, "tol": MM_FP_TOL, MM_FP_EXACT: MM_FP_EXACT, MM_FP_TOL: MM_FP_TOL}[mode]
+        check(self.lib.mm_set_fp_mode(self.handle, m), "mm_set_fp_mode")
+
+    def fp_mode(self):
+        return "tol" if check(self.lib.mm_get_fp_mode(self.handle), "mm_get_fp_mode") == MM_FP_TOL else "exact"
+
+    def last_locate_stats(self):
+        """Of the last hex8 locate stage: solves MM_FP_TOL repeated in the reference's arithmetic, targets that went
+        through the reference-order kernel, targets of a long on-demand list's second pass (synchronises)."""
+        buf = (C.c_longlong * 4)()
+        check(self.lib.mm_last_locate_stats(self.handle, buf), "mm_last_locate_stats")
+        return {"redone_exact": int(buf[0]), "reference_order": int(buf[1]), "second_pass": int(buf[2])}
 
     def last_timings(self):
         """Per-stage milliseconds of the last call (hipEvents on this context's stream)."""

@@ -26,6 +26,8 @@ cache = []
 
 MM_OK = 0
 MM_KNN_MAX_K = 64
+MM_FP_EXACT = 0
+MM_FP_TOL = 1
 STAGES = ("centroid", "knn_build", "knn_query", "locate", "gather", "knn_cell", "locate_pass0")
 
 #: every symbol include/multimesh_hip.h declares (tests check the library exports all of them)
@@ -37,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "mm_centroid", "mm_knn_build", "mm_knn_query", "mm_knn_destroy",
     "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_interpolate_hex8_host", "mm_locate_gll", "mm_gather_elem",
     "mm_scatter_elements", "mm_fluid_solid_fix", "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
+    "mm_set_fp_mode", "mm_get_fp_mode", "mm_last_locate_stats",
 )
 
 
@@ -133,6 +136,12 @@ def load_lib():
     lib.mm_unique_points.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp]
     lib.mm_set_lazy_lists.restype = C.c_int
     lib.mm_set_lazy_lists.argtypes = [vp, C.c_int]
+    lib.mm_set_fp_mode.restype = C.c_int
+    lib.mm_set_fp_mode.argtypes = [vp, C.c_int]
+    lib.mm_get_fp_mode.restype = C.c_int
+    lib.mm_get_fp_mode.argtypes = [vp]
+    lib.mm_last_locate_stats.restype = C.c_int
+    lib.mm_last_locate_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     lib.mm_set_profiling.restype = C.c_int
     lib.mm_set_profiling.argtypes = [vp, C.c_int]
     lib.mm_last_timings.restype = C.c_int

@@ -105,4 +105,63 @@ int64_t nh_compare(int64_t n, const double *pnts, const double *vtxs, void *othe
     *converged = conv;
     return bad;
 }
+
+// MM_FP_TOL: n solves by newton_hex8_fast (cap trips) against other = the oracle's mmo_hex8_newton (the reference
+// iteration, 50 trips).  out[0..2] solves certified accept / certified reject / unsure; out[3] certified verdicts that
+// are WRONG (accept where the reference rejects or the other way round: must be 0); out[4] certified solves whose trip
+// count differs from the reference's; out[5] unsure solves the reference would have accepted.
+// dout[0] largest |xi_fast - xi_ref| / delta over the certified solves, dout[1] largest |xi_fast - xi_ref|, dout[2] the
+// largest delta handed out, dout[3] the largest update ratio |u_i| / |u_i-1| among the certified.
+void nh_fast_stats(int64_t n, const double *pnts, const double *vtxs, void *other, int cap, int64_t *out, double *dout)
+{
+    for (int q = 0; q < 6; ++q) out[q] = 0;
+    for (int q = 0; q < 4; ++q) dout[q] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = pnts + i * 3, *v = vtxs + i * 24;
+        double xo[3] = {0, 0, 0}, xm[3] = {0, 0, 0}, diag[3];
+        int iters = 0;
+        const int ok_o = ((other4_t)other)(p, v, xo, &iters);
+        double worst = 0;
+        for (int q = 0; q < 3; ++q) worst = __builtin_fabs(xo[q]) > worst ? __builtin_fabs(xo[q]) : worst;
+        const bool accept_ref = ok_o && worst < (1 + 0.025);
+        double x[8], y[8], z[8];
+        for (int c = 0; c < 8; ++c) {
+            x[c] = v[c * 3 + 0];
+            y[c] = v[c * 3 + 1];
+            z[c] = v[c * 3 + 2];
+        }
+        const int verdict = newton_hex8_fast(p[0], p[1], p[2], x, y, z, xm, cap, diag);
+        if (verdict == MM_FAST_UNSURE) {
+            ++out[2];
+            if (accept_ref) ++out[5];
+            continue;
+        }
+        ++out[verdict == MM_FAST_ACCEPT ? 0 : 1];
+        if ((verdict == MM_FAST_ACCEPT) != accept_ref) ++out[3];
+        // (a certified verdict claims convergence at trip diag[1]: the reference's count is iters = that trip + 1)
+        if (!ok_o || iters != (int)diag[1] + 1) {
+            ++out[4];
+            continue;
+        }
+        double d = 0;
+        for (int q = 0; q < 3; ++q) d = __builtin_fabs(xo[q] - xm[q]) > d ? __builtin_fabs(xo[q] - xm[q]) : d;
+        if (d / diag[0] > dout[0]) dout[0] = d / diag[0];
+        if (d > dout[1]) dout[1] = d;
+        if (diag[0] > dout[2]) dout[2] = diag[0];
+        if (diag[2] > dout[3]) dout[3] = diag[2];
+    }
+}
+
+// the MM_FP_TOL weights against other = the oracle's mmo_hex8_weights(xi, w): largest absolute difference
+double nh_fast_weights(int64_t n, const double *xis, void (*other)(const double *, double *))
+{
+    double worst = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double xi[3] = {xis[i * 3], xis[i * 3 + 1], xis[i * 3 + 2]}, a[8], b[8];
+        weights_hex8_fast(xi, a);
+        other(xi, b);
+        for (int q = 0; q < 8; ++q) worst = __builtin_fabs(a[q] - b[q]) > worst ? __builtin_fabs(a[q] - b[q]) : worst;
+    }
+    return worst;
+}
 }

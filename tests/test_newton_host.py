@@ -142,3 +142,75 @@ def test_degenerate_inputs_give_the_same_verdicts(host):
         assert bool(ok_o) == bool(ok_m)
         assert np.array_equal(a, b, equal_nan=True)
         assert np.array_equal(np.signbit(a), np.signbit(b)) or np.isnan(a).any()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MM_FP_TOL: newton_hex8_fast must reach the reference's verdict or say "unsure" (csrc/mm_newton_hex8.h)
+# ----------------------------------------------------------------------------------------------------------------------
+def fast_stats(host, pnt, vtx, cap=6):
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags=["C_CONTIGUOUS"])
+    host.nh_fast_stats.restype = None
+    host.nh_fast_stats.argtypes = [C.c_int64, f64p, f64p, C.c_void_p, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64), f64p]
+    out, dout = np.zeros(6, np.int64), np.zeros(4)
+    host.nh_fast_stats(len(pnt), pnt, vtx, C.cast(O.lib().mmo_hex8_newton, C.c_void_p), cap, out, dout)
+    return dict(accept=int(out[0]), reject=int(out[1]), unsure=int(out[2]), wrong=int(out[3]), tripdiff=int(out[4]),
+                unsure_but_acceptable=int(out[5]), worst_over_delta=dout[0], worst=dout[1], max_delta=dout[2], max_ratio=dout[3])
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_fast_solve_never_certifies_a_wrong_verdict(host, case):
+    # every certified accept / reject equals the reference's decision (converged within 50 trips AND max|xi| < 1.025),
+    # the certified solves stop at the reference's trip, and their iterate is within a small fraction of the margin
+    # delta of the reference's -- on mild, strong, Earth-scale, affine and tangled elements alike.  The tangled case
+    # may certify few solves; it must not certify a wrong one.
+    jitter, scale, offset, spread = CASES[case]
+    rng = np.random.default_rng(31000 + case)
+    pnt, vtx = elements(rng, 300_000, jitter, scale, offset, spread)
+    for cap in (6, 9):
+        st = fast_stats(host, pnt, vtx, cap)
+        assert st["wrong"] == 0 and st["tripdiff"] == 0, (case, cap, st)
+        assert st["worst_over_delta"] < 0.25, (case, cap, st)        # measured: 0.001 ... 0.11 (tangled elements)
+        assert st["max_ratio"] <= 0.5                                  # certified solves contract two-fold per trip
+    if case in (0, 2, 3):
+        assert st["unsure"] < 0.01 * len(pnt), st                     # well-shaped elements: nearly everything certified
+    assert st["accept"] + st["reject"] > 0.3 * len(pnt), st
+
+
+def test_fast_solve_on_points_at_the_acceptance_threshold(host):
+    # points placed at max|xi| = 1.025 -+ a few ulps to 1e-7: inside the band the verdict is "unsure", outside it is
+    # certified and right
+    rng = np.random.default_rng(5)
+    n = 100_000
+    vtx = (RST[None] + rng.uniform(-0.15, 0.15, size=(n, 8, 3))) * 0.5
+    xi = rng.uniform(-0.9, 0.9, size=(n, 3))
+    axis = rng.integers(0, 3, size=n)
+    eps = rng.choice([0.0, 1e-15, -1e-15, 1e-13, -1e-13, 1e-10, -1e-10, 1e-7, -1e-7], size=n)
+    xi[np.arange(n), axis] = rng.choice([-1.0, 1.0], size=n) * (1.025 + eps)
+    N = 0.125 * (1 + RST[None, :, 0] * xi[:, None, 0]) * (1 + RST[None, :, 1] * xi[:, None, 1]) * (1 + RST[None, :, 2] * xi[:, None, 2])
+    pnt = np.ascontiguousarray(np.einsum("np,npj->nj", N, vtx))
+    st = fast_stats(host, pnt, np.ascontiguousarray(vtx))
+    assert st["wrong"] == 0 and st["tripdiff"] == 0, st
+    assert st["unsure"] > 0.1 * n and st["accept"] > 0.2 * n and st["reject"] > 0.2 * n, st
+
+
+def test_fast_solve_degenerate_inputs_are_unsure_or_right(host):
+    flat = RST.copy()
+    flat[:, 2] = 0.0
+    cube = RST.copy()
+    pnts, vtxs = [], []
+    for vtx, pnt in [(flat, [0.1, 0.2, 0.0]), (cube, [0.0, 0.0, 0.0]), (cube, [1.0, 1.0, 1.0]), (cube * 0.0, [0.0, 0.0, 0.0]),
+                     (cube, [np.nan, 0.0, 0.0]), (cube * 1e-200, [1e-201, 0, 0]), (cube * 1e150, [1e149, 0, 0]),
+                     (cube + 1e12, [1e12, 1e12, 1e12])]:
+        pnts.append(pnt)
+        vtxs.append(vtx)
+    st = fast_stats(host, np.ascontiguousarray(pnts, float), np.ascontiguousarray(vtxs, float))
+    assert st["wrong"] == 0 and st["tripdiff"] == 0, st
+
+
+def test_fast_weights_agree_with_the_reference_polynomials(host):
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags=["C_CONTIGUOUS"])
+    host.nh_fast_weights.restype = C.c_double
+    host.nh_fast_weights.argtypes = [C.c_int64, f64p, C.c_void_p]
+    xi = np.random.default_rng(2).uniform(-1.03, 1.03, size=(200_000, 3))
+    worst = host.nh_fast_weights(len(xi), xi, C.cast(O.lib().mmo_hex8_weights, C.c_void_p))
+    assert worst < 4e-16

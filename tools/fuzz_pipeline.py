@@ -1,8 +1,10 @@
 """Randomised end-to-end check of mm_interpolate_hex8 against the oracle (cKDTree + C restatement +
 NumPy-order gather): random mesh sizes, shears, anisotropy, k, component counts, target clouds that
 lie inside, on and outside the hull, lazy and eager candidate lists.  Not part of the test suite (it
-takes minutes); prints one line per case and exits non-zero on the first mismatch."""
-import sys, time
+takes minutes); prints one line per case and exits non-zero on the first mismatch.
+FP_MODE=tol in the environment runs the context in MM_FP_TOL: node ids, failed counts and zero rows are still compared
+exactly, weights and values to max(1e-12, 64 eps max|x| / shortest element edge) (the mode's stated tolerance)."""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from multimesh_amd import synth
@@ -14,6 +16,18 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # replay one case of a
 big = len(sys.argv) > 4 and sys.argv[4] == "big"         # meshes up to 120^3 nodes, up to 2 M targets
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = Context(0)
+TOL = os.environ.get("FP_MODE", "exact") == "tol"
+ctx.set_fp_mode("tol" if TOL else "exact")
+redone = solves_guess = 0
+EDGES = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]   # exodus order
+
+
+def tolerance(pa, ca):
+    v = pa[ca]
+    hmin = min(np.linalg.norm(v[:, a] - v[:, b], axis=1).min() for a, b in EDGES)
+    return max(1e-12, 64 * 2.220446049250313e-16 * np.abs(pa).max() / hmin)
+
+
 t_start = time.time()
 for case in range(ncases):
     n = int(rng.integers(60, 121)) if big else int(rng.integers(4, 42))
@@ -46,13 +60,24 @@ for case in range(ncases):
     nn = nn.reshape(npts, k)
     enc_o, w_o, nf_o, status = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb, want_status=True)
     ok = status >= 0
-    good = (nf == nf_o == nf2 and np.array_equal(enc.numpy()[ok], enc_o[ok]) and np.array_equal(w.numpy()[ok], w_o[ok])
+    tol = tolerance(pa, ca) if TOL else 0.0
+    if TOL:
+        redone += ctx.last_locate_stats()["redone_exact"]
+        solves_guess += npts
+    same_w = (np.abs(w.numpy()[ok] - w_o[ok]).max(initial=0.0) <= tol) if TOL else np.array_equal(w.numpy()[ok], w_o[ok])
+    good = (nf == nf_o == nf2 and np.array_equal(enc.numpy()[ok], enc_o[ok]) and same_w
             and not enc.numpy()[~ok].any() and not w.numpy()[~ok].any())
     enc_z, w_z = enc_o.copy(), w_o.copy()
     enc_z[~ok] = 0
     w_z[~ok] = 0
     ref_vals = O.gather(fields, enc_z, w_z)
-    good = good and vals.numpy().tobytes() == ref_vals.tobytes() and vals2.numpy().tobytes() == ref_vals.tobytes()
+    if TOL:
+        vtol = tol * 8 * np.abs(fields).max()
+        good = good and np.abs(vals.numpy() - ref_vals).max(initial=0.0) <= vtol and np.abs(vals2.numpy() - ref_vals).max(initial=0.0) <= vtol
+        # rows of failed points are produced by the exact kernel: bit-equal, sign of zero included
+        good = good and vals.numpy()[~ok].tobytes() == ref_vals[~ok].tobytes() and vals2.numpy()[~ok].tobytes() == ref_vals[~ok].tobytes()
+    else:
+        good = good and vals.numpy().tobytes() == ref_vals.tobytes() and vals2.numpy().tobytes() == ref_vals.tobytes()
     print(f"case {case:3d} n={n:2d} N={npts:6d} k={k:2d} C={ncomp} lazy={int(lazy)} margin={margin} "
           f"nfailed={nf:6d} fallback={(status >= k).sum():5d} -> {'ok' if good else 'MISMATCH'}", flush=True)
     if not good:
@@ -82,4 +107,4 @@ for case in range(ncases):
             t = idx_ok[r]
             print("   target", t, "status", status[t], "gpu ids", e[t], "ref ids", enc_o[t])
         sys.exit(1)
-print(f"{ncases} cases ok in {time.time() - t_start:.0f} s")
+print(f"{ncases} cases ok in {time.time() - t_start:.0f} s" + (f" (MM_FP_TOL: {redone} solves repeated exactly for {solves_guess} targets)" if TOL else ""))
