@@ -122,10 +122,22 @@ def gll_bytes(n_targets, n_elem, P, dim, k, ncomp):
 #: rocprofv3 --kernel-trace prints for them (profiles/*_kernel_stats.csv)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
 KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_lane_kernel<8, int>",
-                   "locate_pass0": "locate_pass_kernel<true, int, true, int>", "gather": "gather8_kernel<true>"}
+                   "locate_pass0": "locate_pass_kernel<true, int, true, int, true>", "gather": "gather8_kernel<true>"}
+LOCATE_KERNEL = {"tol": "locate_pass_kernel<true, int, true, int, true>", "exact": "locate_pass_kernel<true, int, true, int, false>"}
 #: what the counters say limits each of them: the two big kernels sit on the vector-issue
 #: floor, the streaming ones on HBM
 BOUND_OF_STAGE = {"centroid": "hbm", "knn_cell": "valu", "locate_pass0": "valu", "gather": "hbm"}
+#: ... the locate pass by mode: the reference's arithmetic is bound by fp64 issue, the MM_FP_TOL one by the L1's misses in
+#: flight (profiles/r04_mem_counters_tol.json: ~55 line requests outstanding per CU at ~560 cycles each)
+LOCATE_BOUND = {"tol": "l1_miss_concurrency", "exact": "valu"}
+METRIC_OF_WORKLOAD = {
+    "metric": "interpolated points/sec, 10M->10M 3D mesh, 1 scalar field",
+    "cfg2": "interpolated points/sec, 1M->1M 3D hex mesh, 1 scalar field (BASELINE configs[1])",
+    "cfg3": "interpolated points/sec, 10M->10M 3D mesh, 3-component vector field (BASELINE configs[2])",
+    "cfg4": "interpolated points/sec, 100M-target / 10M-source 3D mesh, one of 8 target shards per GPU (BASELINE configs[3])",
+}
+TOL_STATEMENT = ("MM_FP_TOL: node ids and failed count bit-identical to the reference; weights within 1e-12 (absolute, they are O(1)) "
+                 "and values within 1e-12 * 8 * max|field| -- in general max(1e-12, 64 eps max|x| / shortest element edge)")
 #: key of the kernel in profiles/*_knn_counters.json
 COUNTER_KEY = {"knn_cell": "knn_lane_kernel", "locate_pass0": "locate_pass_kernel"}
 SINGLE_KERNEL_STAGES_TIMED_LIVE = ("knn_cell", "locate_pass0")   # mm_set_profiling(ctx, 2)
@@ -190,6 +202,42 @@ def valu_floor(stage, ms, scale=1.0, pattern="*_knn_counters.json", key=None, ke
                 "note": "floor = (fast-class insts x fast cycles + the rest x slow cycles) / 1024 SIMDs / clock; "
                         "counts from the committed counter passes of the metric workload, not re-measured in this run"}
     except Exception as exc:   # a malformed profile must not break the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def counter_profile_mode():
+    """The fp mode the newest committed counter profile of the metric workload was taken in ("tol" / "exact"; profiles
+    before round 4 are all "exact")."""
+    f = _latest("*_knn_counters.json")
+    if not f:
+        return None
+    try:
+        return json.load(open(f)).get("_fp_mode", "exact")
+    except Exception:
+        return None
+
+
+def memory_side_profile(stage, ms):
+    """What the TA / TCP counters of the committed pass say about the dominant kernel (profiles/*_mem_counters*.json,
+    tools/mem_counters.sh): L1 -> L2 read requests per launch, their mean latency, and by Little's law the line requests
+    in flight per CU -- the quantity that bounds a gather-heavy kernel when the vector pipes are idle."""
+    f = _latest("*_mem_counters*.json")
+    key = COUNTER_KEY.get(stage)
+    if not (f and key):
+        return None
+    try:
+        c = json.load(open(f)).get(key, {})
+        req, lat = c["TCP_TCC_READ_REQ_sum"], c["TCP_TCC_READ_REQ_LATENCY_sum"]
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                # per XCD
+        return {"kernel": KERNEL_OF_STAGE[stage], "l1_to_l2_read_requests_per_launch": round(req),
+                "mean_read_latency_cycles": round(lat / req, 1), "cus": 256,
+                "read_requests_in_flight_per_cu": round(lat / (cycles * 256.0), 1),
+                "tcp_pending_stall_share": round(c.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / (cycles * 256.0), 3),
+                "ta_busy_share": round(c.get("TA_TA_BUSY_sum", 0.0) / (cycles * 256.0), 3),
+                "source": os.path.relpath(f, ROOT),
+                "note": "from the committed counter passes of the metric workload (one rocprofv3 pass per small group), not "
+                        "re-measured in this run; requests in flight = sum of request latencies / (kernel cycles x 256 CUs)"}
+    except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
@@ -290,8 +338,16 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--cfg4-shard", type=int, default=0, help="cfg4 at one rank: which of the 8 shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-weak-beside", action="store_true", help="strong scaling at N > 1: skip the weak-scaling side run")
+    ap.add_argument("--weak-beside", action="store_true",
+                    help="strong scaling at N > 1: also make the short weak-scaling side run (every rank a full target mesh)")
+    ap.add_argument("--no-weak-beside", action="store_true", help="(the default since round 4; kept for old command lines)")
     ap.add_argument("--cpu-sample-stride", type=int, default=0)
+    ap.add_argument("--fp-mode", default="tol", choices=("tol", "exact"),
+                    help="arithmetic of the hex8 locate stage (mm_set_fp_mode): tol = certified fast Newton, node ids bit-exact, "
+                         "values to 1e-12 (north_star's contract; the default); exact = the reference's operations, 0 ulp")
+    ap.add_argument("--as-rank", default="", metavar="r/G",
+                    help="PROJECTION, one process, no process group: run exactly rank r's share of a G-rank strong-scaling "
+                         "run of the workload alone on this GPU (tools/strong_projection.py loops over r and G)")
     return ap.parse_args(argv)
 
 
@@ -481,6 +537,20 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
     k = args.k
     sharded = args.workload == "cfg4"
     scaling = args.scaling if args.scaling != "auto" else ("weak" if sharded else "strong")
+    # --as-rank r/G: this single process plays rank r of a G-rank strong-scaling run, alone on its GPU (a PROJECTION of
+    # what that rank's step would cost: no process group, no collective)
+    as_rank = bool(args.as_rank)
+    proj_rank, proj_world = 0, world
+    if as_rank:
+        try:
+            proj_rank, proj_world = (int(v) for v in args.as_rank.split("/"))
+            assert 0 <= proj_rank < proj_world
+        except Exception:
+            print("bench.py: --as-rank wants r/G with 0 <= r < G", file=sys.stderr)
+            return 2
+        if world != 1 or sharded or scaling != "strong":
+            print("bench.py: --as-rank is a one-process projection of a strong-scaling rank (not cfg4, --gpus 1)", file=sys.stderr)
+            return 2
     if sharded and scaling == "strong":
         if rank == 0:
             print("bench.py: cfg4 is one fixed shard per rank (weak scaling by construction)", file=sys.stderr)
@@ -509,15 +579,17 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
                        f"mesh (rows {lo}..{hi}: a {(hi - 1) // n_tgt ** 2 - lo // n_tgt ** 2 + 1}-plane slab), rank r <-> shard r")
     elif scaling == "strong":
         def bounds(r):
-            return shard_bounds(n_all, world, r)
+            return shard_bounds(n_all, proj_world, proj_rank if as_rank else r)
 
         def tgt_rows(r, a, b):
             return synth.hex_mesh_rows(n_tgt, bounds(r)[0] + a, bounds(r)[0] + b, seed=7)
 
-        chunk = -(-n_all // world)
+        chunk = -(-n_all // proj_world)
         lo, hi = bounds(rank)
         target_desc = (f"ONE {n_tgt}^3 = {n_all}-node target mesh (jitter seed 7)" +
-                       (f", rank r takes rows shard_bounds({n_all}, {world}, r) (this rank: {lo}..{hi})" if world > 1 else ""))
+                       (f", rank r takes rows shard_bounds({n_all}, {world}, r) (this rank: {lo}..{hi})" if world > 1 else "") +
+                       (f"; PROJECTION: rows shard_bounds({n_all}, {proj_world}, {proj_rank}) = {lo}..{hi}, the share of rank "
+                        f"{proj_rank} of {proj_world}, run alone" if as_rank else ""))
     else:
         def bounds(r):
             return 0, n_all
@@ -541,6 +613,9 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(dev_index, stream=stream)
+    ctx.set_fp_mode(args.fp_mode)
+    KERNEL_OF_STAGE["locate_pass0"] = LOCATE_KERNEL[args.fp_mode]
+    BOUND_OF_STAGE["locate_pass0"] = LOCATE_BOUND[args.fp_mode]
     # Stage timers cost the stream two events per stage (~5 us each between kernels, ~40 us per step for all seven):
     # during the timed steps only the two dominant kernels are timed (the roofline's durations, live, over the
     # timed region); the other stages' table comes from STAGE_TABLE_STEPS extra, untimed steps after it.
@@ -596,6 +671,32 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
             stage_ms[s] = table[s] / STAGE_TABLE_STEPS * max(args.steps, 1)
     nfailed_total = D.all_sum_int(st["nfailed"])
     t_out, t_all = st["outs"][st["last"]], st["alls"][st["last"]]
+    locate_stats = ctx.last_locate_stats()      # of the last step: solves MM_FP_TOL repeated in the reference's arithmetic
+    # the other arithmetic beside it (a few untimed-region steps on the same inputs): what the mode buys
+    other_mode = None
+    if rank == 0 and not as_rank:
+        other = "exact" if args.fp_mode == "tol" else "tol"
+        ctx.set_fp_mode(other)
+        o_out = torch.zeros((chunk, ncomp), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, out=o_out[:n_local])
+        torch.cuda.synchronize()
+        o_ms, o_pass = 0.0, 0.0
+        o_steps = 5
+        t0 = time.perf_counter()
+        for _ in range(o_steps):
+            ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, out=o_out[:n_local])
+            o_pass += ctx.last_timings()["locate_pass0"]
+        torch.cuda.synchronize()
+        o_ms = (time.perf_counter() - t0) / o_steps * 1e3
+        diff = float((o_out[:n_local] - t_out[:n_local]).abs().max().item()) if n_local else 0.0
+        other_mode = {"mode": other, "ms_per_step": round(o_ms, 4), "locate_pass0_ms": round(o_pass / o_steps, 4),
+                      "kernel": LOCATE_KERNEL[other], "steps": o_steps,
+                      "max_abs_difference_of_the_interpolated_values": diff,
+                      "note": "the same step in the other arithmetic of mm_set_fp_mode, wall clock over a few steps after the "
+                              "timed region (single rank, no collective)"}
+        ctx.set_fp_mode(args.fp_mode)
+        del o_out
 
     # ---- the collective by itself: a BLOCKING all-gather, timed on the stream; then the WHOLE gathered field
     # against what one rank computes alone ----
@@ -639,7 +740,7 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
 
     # ---- strong scaling: the weak-scaling figure beside it (every rank a full target mesh of its own) ----
     weak = None
-    if use_dist and scaling == "strong" and world > 1 and not args.no_weak_beside:
+    if use_dist and scaling == "strong" and world > 1 and args.weak_beside:
         pw = torch.from_numpy(synth.hex_mesh_rows(n_tgt, 0, n_all, seed=7 + rank)).to(dev)
         wargs = argparse.Namespace(steps=min(args.steps, 5), warmup=min(args.warmup, 2))
         stw, stepw, drainw = make_run(pw, n_all, n_all)
@@ -702,17 +803,28 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
                     "note": "priced against the HBM roofline as SURVEY 8(d) asks (`bound`); `limited_by` is what the "
                             "counters say actually limits the kernel -- for the kNN and locate kernels the vector-issue "
                             "rate, quantified in roofline_valu"}
-        scale = n_local / 10_077_696.0      # the counter passes were taken on the metric workload
-        roofline_valu = {s: valu_floor(s, stages[s]["ms"], scale) for s in ("knn_cell", "locate_pass0")
-                         if stages[s].get("ms")}
+        # VALU-issue floors: only for the launch the counter passes were taken on (the metric workload, one rank, the
+        # mode the profile names) -- rescaled counts put "floors" above the measured time on other workloads
+        roofline_valu = None
+        counters_mode = counter_profile_mode()
+        if args.workload == "metric" and world == 1 and not as_rank and n_local == 10_077_696:
+            roofline_valu = {s: valu_floor(s, stages[s]["ms"]) for s in ("knn_cell", "locate_pass0")
+                             if stages[s].get("ms") and (s != "locate_pass0" or counters_mode == args.fp_mode)}
+            for v in roofline_valu.values():
+                if v and v.get("frac") and v["frac"] > 1.0:     # a floor above the measured time is not a floor
+                    v["note"] = "counter profile does not match this build: " + v.get("note", "")
+                    v["frac"] = None
         e2e_bytes = 952 + 72 * (ncomp - 1)          # 184 + 568 + 200 at C = 1, k = 20 (+72 per component)
         e2e_bytes += 8 * (k - 20) * 2
         replicated_ms = stages["centroid"]["ms"] + stages["knn_build"]["ms"]
         line = {
-            "metric": "interpolated points/sec, 10M->10M 3D mesh, 1 scalar field",
+            "metric": METRIC_OF_WORKLOAD.get(args.workload, METRIC_OF_WORKLOAD["metric"]),
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "projection": ({"as_rank": f"{proj_rank}/{proj_world}",
+                            "note": "NOT a scaling measurement: one process ran rank r's share of a G-rank strong-scaling step alone "
+                                    "(no process group, no collective); tools/strong_projection.py"} if as_rank else None),
             "config": {"workload": f"{args.workload}: hex8 3D {n_nodes} source nodes -> {total_targets} targets in all, "
                                    f"{n_local} on rank 0 (n_src={n_src}, n_tgt={n_tgt} per side, jittered unit cube), "
                                    f"{ncomp} field component(s), k={k}; targets: " + target_desc,
@@ -726,8 +838,17 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
                                        f"step over {D.backend} (asynchronous: overlaps the next step's kernels)")
                        if use_dist else "single GPU"},
             "nfailed": nfailed_total,
+            "fp_mode": {"mode": args.fp_mode,
+                        "tolerance": TOL_STATEMENT if args.fp_mode == "tol" else "0 ulp: every output bit-identical to the reference",
+                        "solves_repeated_in_the_reference_arithmetic": locate_stats["redone_exact"],
+                        "share_of_targets": round(locate_stats["redone_exact"] / max(n_local, 1), 5),
+                        "targets_through_the_reference_order_kernel": locate_stats["reference_order"],
+                        "other_mode": other_mode},
             "roofline": roofline,
-            "roofline_valu": roofline_valu,
+            "roofline_valu": roofline_valu if roofline_valu is not None else {
+                "omitted": "instruction-count floors are only printed for the launch the committed counter passes were taken on "
+                           "(--workload metric, one rank)"},
+            "roofline_memory_side": memory_side_profile(dominant, stages[dominant]["ms"]) if args.workload == "metric" else None,
             "roofline_end_to_end": {"algorithmic_bytes_per_target": e2e_bytes,
                                     "achieved_GBps_per_gpu": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -761,7 +882,10 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
         g_ms /= reps
         ga = account(g_ms, n_local * (128 + 72 * ncomp), n_local * (128 + 8 * ncomp) + n_nodes * 8 * ncomp)
         ga["kernel"] = "gather8_kernel<true>"
-        ga["equals_fused_values"] = bool(np.array_equal(g_out.numpy(), t_out[:n_local].cpu().numpy()))
+        g_diff = float(np.abs(g_out.numpy() - t_out[:n_local].cpu().numpy()).max()) if n_local else 0.0
+        # (MM_FP_TOL forms the fused sum as a chain of fused multiply-adds: equal to the gather kernel's NumPy-order sum to rounding)
+        ga["equals_fused_values"] = bool(g_diff == 0.0) if args.fp_mode == "exact" else bool(g_diff <= 1e-12 * 8 * float(np.abs(fields).max()))
+        ga["max_abs_diff_vs_fused_values"] = g_diff
         ga["traffic"] = measured_traffic("gather")
         ga["note"] = ("mm_gather on the (node ids, weights) rows of this run's targets: section 8(d) prices 64 B of gathered "
                       "field values per target and component, which are L2 hits (each node serves ~8 targets); actual_bytes "
@@ -770,7 +894,7 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
         stages["gather_reapply"] = ga
         del vals_op, enc, w, g_out
 
-        if world == 1:
+        if world == 1 and not as_rank:
             # PCIe-inclusive rate (never `value`): the same step fed from HOST arrays, i.e. what the
             # legacy host-pointer boundary costs: H2D of mesh + targets + field, D2H of the result
             out_h = np.zeros((n_local, ncomp))          # the reference's callers pass zero-initialised outputs (cli.py:77-78)
@@ -785,14 +909,28 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
                                    "note": "mm_interpolate_hex8_host: one step fed from pageable NumPy arrays (H2D on a second "
                                            "stream beside the kernels + D2H), device copies cached in the context; not `value`"}
             del vals_h
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not as_rank:
             stride = args.cpu_sample_stride or max(1, n_local // 2_500_000)   # ~12 s of single-threaded CPU work
             base, (stride, enc_c, w_c, vals_c) = cpu_baseline(pa, ca, pb, fields, k, stride)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu_baseline"] = value / base["value"]
-            # parity gate on the sample the CPU just computed
+            # parity gate on the sample the CPU just computed: node ids exactly, always; values bit for
+            # bit in MM_FP_EXACT, within the stated tolerance in MM_FP_TOL (weights too)
             got = t_out[:n_local].cpu().numpy()[::stride]
-            line["parity_vs_cpu_sample"] = bool(np.array_equal(got, vals_c))
+            _, enc_g, w_g, _ = ctx.interpolate_hex8(t_nodes, t_conn, t_pts, t_fields, nelem_to_search=k, want_operator=True)
+            enc_s, w_s = enc_g.numpy()[::stride], w_g.numpy()[::stride]
+            ids_equal = bool(np.array_equal(enc_s, enc_c))
+            if args.fp_mode == "exact":
+                vals_ok = bool(np.array_equal(got, vals_c)) and bool(np.array_equal(w_s, w_c))
+            else:
+                vals_ok = (float(np.abs(got - vals_c).max()) <= 1e-12 * 8 * float(np.abs(fields).max())
+                           and float(np.abs(w_s - w_c).max()) <= 1e-12)
+            line["parity_vs_cpu_sample"] = ids_equal and vals_ok
+            line["parity_detail"] = {"node_ids_bit_equal": ids_equal, "values_within_stated_tolerance": vals_ok,
+                                     "max_abs_value_diff": float(np.abs(got - vals_c).max()),
+                                     "max_abs_weight_diff": float(np.abs(w_s - w_c).max()),
+                                     "sample_points": int(len(got)), "mode": args.fp_mode}
+            del enc_g, w_g
             if not line["parity_vs_cpu_sample"]:
                 rc = 1
         out.emit(json.dumps(line))
@@ -958,7 +1096,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
             line["allgather"] = allgather
             if allgather.get("gathered_equals_single_rank") is False:
                 rc = 1
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not as_rank:
             # the oracle's restatement of the same loop on a bounded sample ("port": salvus.fem is absent)
             from oracle import oracle as O
             from scipy.spatial import cKDTree

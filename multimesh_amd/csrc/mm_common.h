@@ -104,6 +104,12 @@ struct mm_context {
         int misses = 0;
         long long calls_guessed = 0;   // (mm_debug_grid_guess: what the tests look at)
     } grid_guess;
+    // kNN queries whose targets fill only part of the grid (knn_query_typed): the verdict of the occupied-strip statistic
+    struct {
+        bool valid = false;
+        i64 npts = 0, ncells = 0;
+        bool dense = false;
+    } lane_hint;
     hipStream_t copy_stream = nullptr;   // host-array entry points: uploads run beside the kernels (created on first use)
     hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr};
 };

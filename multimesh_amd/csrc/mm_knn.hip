@@ -1914,6 +1914,8 @@ constexpr int kLanePad = 16;           // far-away entries behind the tile (a wi
 constexpr int kLaneZ = 7;              // cells per strip: ~57 targets per round of 64 lanes at 8 targets per cell
 constexpr int kLaneZMax = 12;
 constexpr int kLaneRounds = 4;         // rounds (of 64 targets) per work item
+constexpr i64 kLaneProbeMin = 32768;              // queries at least this large whose targets are sparse ON AVERAGE are looked at more closely:
+constexpr i64 kLaneProbeTargetsPerItem = 16;      // ... the lane kernel serves them when a work item holds at least this many targets
 // (the packed prefix sums of the cell counts give each half 16 bits: counts are clamped to kLaneTileCap + 1, the lower
 // word sums 64 of them, the upper one the rest of the (Z + 2) x 9 cells)
 static_assert(64 * (kLaneTileCap + 1) < 65536 && ((kLaneZMax + 2) * 9 - 64) * (kLaneTileCap + 1) < 65536,
@@ -3156,7 +3158,18 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     // MM_KNN_KERNEL=lane|strip|cell forces a kernel (tuning and tests only).
     static const char *force_kernel = getenv("MM_KNN_KERNEL");
     LaneWork lane_work;
-    bool use_lane = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK && npts >= 2 * ix->ncells;
+    const bool lane_base = !ix->fine && ix->dims[2] >= 6 && k <= kLaneMaxK;
+    bool use_lane = lane_base && npts >= 2 * ix->ncells;
+    // Targets that fill only a part of the grid -- one rank's share of a sharded target set: a slab with the full problem's
+    // density inside it and nothing outside -- fail the average test above although every strip that holds targets is as
+    // full as ever (round 4: a 1/8 shard of the metric's targets took 3.1 ms in the strip kernel, 0.25 ms here).  What
+    // matters is targets per OCCUPIED strip, which only the device knows after the sort: the first query of a context
+    // with these sizes reads the number of work items back (one small wait) and the verdict is kept for the next ones.
+    bool lane_probe = false;
+    if (lane_base && !use_lane && npts >= kLaneProbeMin && !getenv("MM_KNN_KERNEL")) {
+        if (ctx->lane_hint.valid && ctx->lane_hint.npts == npts && ctx->lane_hint.ncells == ix->ncells) use_lane = ctx->lane_hint.dense;
+        else lane_probe = use_lane = true;   // (set up as for the lane kernel; decided after the targets are sorted)
+    }
     // with density levels: level 0 only (every target starts there; strips too full for the tile are passed
     // down), and only for the short lists the lane kernel is best at
     static const bool lane_level0 = !(getenv("MM_KNN_LANE_LEVEL0") && atoi(getenv("MM_KNN_LANE_LEVEL0")) == 0);
@@ -3166,9 +3179,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     // (MM_KNN_FORCE_LIST here and MM_KNN_LEVELS / MM_KNN_PER_CELL in the build are read per call on purpose: tests switch them
     // inside one process; every other knob is read once)
     const bool force_list = getenv("MM_KNN_FORCE_LIST") != nullptr;
-    if (force_list || list0) use_lane = false;
+    if (force_list || list0) use_lane = lane_probe = false;
     static const bool unsorted_rows = getenv("MM_KNN_UNSORTED_ROWS") != nullptr;
-    const bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !unsorted_rows;
+    bool sorted_rows = use_lane && !ix->fine && tsorted_out != nullptr && !unsorted_rows;
     lane_work.sorted_rows = sorted_rows ? 1 : 0;
     if (use_lane) {
         static const int force_z = getenv("MM_KNN_LANE_Z") ? atoi(getenv("MM_KNN_LANE_Z")) : 0;
@@ -3235,7 +3248,7 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             // (outlives this call's scratch: the locate stage reads it)
             int brc = mm_buffer_get(ctx, MM_BUF_TSORTED, (size_t)npts * kRec * sizeof(double), (void **)&tsorted);
             if (brc != MM_OK) return brc;
-            *tsorted_out = tsorted;
+            if (!lane_probe) *tsorted_out = tsorted;
         } else {
             tsorted = (double *)mm_scratch_take(ctx, (size_t)npts * kRec * sizeof(double));
         }
@@ -3257,6 +3270,26 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
         launch_scan_tail(ctx, counts, ncells, tile_sums, ntiles, start);
         hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim, gl,
                            start, tsorted, list, list_count);
+        if (lane_probe && level == 0) {
+            // targets per occupied strip: the work-item count of the lane kernel's own prepass, read back once
+            const int per_item = kWave * kLaneRounds;
+            const int nt = (int)((lane_work.nstrips_total + kScanTile - 1) / kScanTile);
+            hipLaunchKernelGGL(lane_items_sums_kernel, dim3(nt), dim3(kBlock), 0, ctx->stream, gl, start, lane_work.Z, per_item,
+                               lane_work.nstrips_total, lane_work.tile_sums, lane_work.items, lane_work.max_items);
+            hipLaunchKernelGGL(lane_items_offsets_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, lane_work.tile_sums, nt);
+            MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 2, lane_work.tile_sums + nt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            const i64 items = (i64) * reinterpret_cast<const int *>(ctx->h_counters + 2);
+            use_lane = items > 0 && npts >= kLaneProbeTargetsPerItem * items;
+            ctx->lane_hint.valid = true;
+            ctx->lane_hint.npts = npts;
+            ctx->lane_hint.ncells = ix->ncells;
+            ctx->lane_hint.dense = use_lane;
+            lane_probe = false;
+            sorted_rows = sorted_rows && use_lane;
+            lane_work.sorted_rows = sorted_rows ? 1 : 0;
+            if (sorted_rows) *tsorted_out = tsorted;
+        }
 #define MM_FAST(KK)                                                                                                  \
     launch_fast<KK, IDX>(ctx, l, gl, pts_d, npts, kout, start, tsorted, idx_d, dist_d, fb_list, fb_count, down_list, \
                          down_count, level == 0, strip_list, strip_count, use_lane && level == 0 ? &lane_work : nullptr)

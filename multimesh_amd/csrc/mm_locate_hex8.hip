@@ -80,20 +80,26 @@ struct CornersT {
 };
 typedef CornersT<i64> Corners;
 
+// the element's eight node ids in the locator's corner order ...
 template <bool EXODUS, typename ID>
-__device__ __forceinline__ void load_corners(const i64 *__restrict__ conn,
-                                             const double *__restrict__ nodes, i64 elem, CornersT<ID> &c)
+__device__ __forceinline__ void load_ids(const i64 *__restrict__ conn, i64 elem, ID (&id)[8])
 {
     const longlong2 *row = reinterpret_cast<const longlong2 *>(conn + elem * 8);
     const longlong2 a = row[0], b = row[1], cc = row[2], d = row[3];
-    c.id[0] = (ID)a.x;
-    c.id[1] = (ID)(EXODUS ? b.y : a.y);  // reference scripts/cli.py:79-81: columns 1 and 3 swap
-    c.id[2] = (ID)b.x;
-    c.id[3] = (ID)(EXODUS ? a.y : b.y);
-    c.id[4] = (ID)cc.x;
-    c.id[5] = (ID)cc.y;
-    c.id[6] = (ID)d.x;
-    c.id[7] = (ID)d.y;
+    id[0] = (ID)a.x;
+    id[1] = (ID)(EXODUS ? b.y : a.y);  // reference scripts/cli.py:79-81: columns 1 and 3 swap
+    id[2] = (ID)b.x;
+    id[3] = (ID)(EXODUS ? a.y : b.y);
+    id[4] = (ID)cc.x;
+    id[5] = (ID)cc.y;
+    id[6] = (ID)d.x;
+    id[7] = (ID)d.y;
+}
+
+// ... and their coordinates
+template <typename ID>
+__device__ __forceinline__ void load_xyz(const double *__restrict__ nodes, CornersT<ID> &c)
+{
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const double *p = nodes + (i64)c.id[n] * 3;
@@ -101,6 +107,14 @@ __device__ __forceinline__ void load_corners(const i64 *__restrict__ conn,
         c.y[n] = p[1];
         c.z[n] = p[2];
     }
+}
+
+template <bool EXODUS, typename ID>
+__device__ __forceinline__ void load_corners(const i64 *__restrict__ conn,
+                                             const double *__restrict__ nodes, i64 elem, CornersT<ID> &c)
+{
+    load_ids<EXODUS>(conn, elem, c.id);
+    load_xyz(nodes, c);
 }
 
 __device__ __forceinline__ double max_abs3(const double (&xi)[3])
@@ -278,6 +292,15 @@ constexpr int kPassBlock = 256;
 #ifndef MM_PASS_WAVES   // tuning builds only: minimum waves per SIMD the register allocator must leave room for
 #define MM_PASS_WAVES 2
 #endif
+#ifndef MM_PASS_PREFETCH   // 1: a fresh batch's targets, first candidates and their connectivity rows are requested a
+#define MM_PASS_PREFETCH 0  //    round ahead (measured: no faster -- the pass is bound by its L1 misses in flight, not by the chain)
+#endif
+#ifndef MM_DRAIN_SLOW_FIRST   // at the end of a wave's input: slow tiers' leftovers before the ordinary drain rounds
+#define MM_DRAIN_SLOW_FIRST 0
+#endif
+#ifndef MM_DRAIN_G8           // drain rounds with at most this many targets try 8 candidates per target at once (0: never)
+#define MM_DRAIN_G8 0
+#endif
 #ifndef MM_FAST_WAVES   // ... for the MM_FP_TOL instances
 #define MM_FAST_WAVES 2
 #endif
@@ -431,6 +454,43 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
         }
     };
     advance();
+    // A ROUND AHEAD (MM_PASS_PREFETCH): a fresh batch needs its targets' records, their first candidates, those elements'
+    // connectivity rows and then the corner coordinates -- four dependent round trips before the first multiplication,
+    // and with the cheap MM_FP_TOL solve the pass waits for memory 70 % of its wave-cycles.  The batch a wave will
+    // take next is known as soon as it takes one, so its records and first candidates are requested then (stage a) and
+    // the connectivity rows at the end of that round (stage b: the candidates have arrived by then); they land while
+    // the wave works on other rounds and wait in 17 registers: a fresh round starts at the corner coordinates.
+    const bool pf_on = MM_PASS_PREFETCH && !in_list;
+    double pf_p[4] = {0., 0., 0., 0.};
+    int pf_elem = -1;
+    NID pf_id[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool need_b = false;   // (wave-uniform)
+    auto prefetch_a = [&]() {
+        const i64 q = next + lane;
+        if (q < total) {   // (next == total: no batch left, nothing is requested)
+            if (SORTED) {
+                const double2 *r2 = reinterpret_cast<const double2 *>(pts + q * 4);
+                const double2 xy = r2[0], zw = r2[1];
+                pf_p[0] = xy.x;
+                pf_p[1] = xy.y;
+                pf_p[2] = zw.x;
+                pf_p[3] = zw.y;
+            } else {
+                pf_p[0] = pts[q * 3 + 0];
+                pf_p[1] = pts[q * 3 + 1];
+                pf_p[2] = pts[q * 3 + 2];
+            }
+            pf_elem = j0 < k ? (int)nn[q * k + j0] : -1;
+        }
+    };
+    auto prefetch_b = [&]() {
+        const i64 q = next + lane;
+        if (q < total && pf_elem >= 0 && !(nelem > 0 && (i64)pf_elem >= nelem)) load_ids<EXODUS>(conn, (i64)pf_elem, pf_id);
+    };
+    if (pf_on) {
+        prefetch_a();
+        prefetch_b();
+    }
 #ifdef MM_LOCATE_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
@@ -446,6 +506,10 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
         double xi_in[3] = {0., 0., 0.};   // tiers 1 and 2: the iterate the solve stopped at under the tier below's cap
         int tier = 0;          // whose cap this round's solves run under
         int lgG = 0;           // log2 of the lanes per target (only the drain rounds work ahead)
+        bool fresh = false;    // this round's targets and first candidates wait in the prefetch registers
+        double cur_p[4] = {0., 0., 0., 0.};
+        int cur_elem = -1;
+        NID cur_id[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (held2 >= 64 || held1 >= 64 || held0 >= 64) {
             int from;
             if (held2 >= 64) {
@@ -474,29 +538,27 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
             if (active) {
                 i = in_list ? (i64)in_list[q] : q;
             }
+            if (pf_on) {
+                fresh = true;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) cur_p[a] = pf_p[a];
+                cur_elem = pf_elem;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) cur_id[n] = pf_id[n];
+            }
             advance();
+            if (pf_on) {
+                prefetch_a();
+                need_b = true;
+            }
 #ifdef MM_EXP_NODRAIN   // timing experiment only (results are wrong): how long the drain at the end of the pass takes
         } else if (true) {
             break;
 #endif
-        } else if (held0 > 0) {
-            // input exhausted: drain what is left with partly filled waves (63 -> ~22 -> ~8 -> ...: a
-            // handful of short rounds at the very end of the pass instead of another pass).  The idle
-            // lanes work ahead: with at most 32 (16) targets left, 2 (4) lanes per target try its
-            // next 2 (4) candidates at once, which shortens the chain of rounds a hard target needs;
-            // the group then acts on the first candidate, in order, that is not a plain rejection.
-            lgG = held0 <= 16 ? 2 : (held0 <= 32 ? 1 : 0);
-            const int entry = lane >> lgG;
-            active = entry < held0;
-            if (active) {
-                const int2 e = my_q0[entry];
-                i = e.x;
-                j = e.y + (lane & ((1 << lgG) - 1));
-            }
-            held0 = 0;
-        } else if (held1 > 0 || held2 > 0) {
-            // ... then the slow solves that are left, one lane each
-            tier = held1 > 0 ? 1 : 2;
+        } else if ((held1 > 0 || held2 > 0) && (MM_DRAIN_SLOW_FIRST || held0 == 0)) {
+            // input exhausted: the slow solves that are left, one lane each -- the slowest tier first, so that what they
+            // reject joins the drain rounds below instead of starting another chain of rounds behind them
+            tier = MM_DRAIN_SLOW_FIRST ? (held2 > 0 ? 2 : 1) : (held1 > 0 ? 1 : 2);
             active = lane < (tier == 1 ? held1 : held2);
             if (active) {
                 const int2 e = (tier == 1 ? my_q1 : my_q2)[lane];
@@ -509,6 +571,21 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
             }
             if (tier == 1) held1 = 0;
             else held2 = 0;
+        } else if (held0 > 0) {
+            // ... then what is left of the ordinary retries, with partly filled waves (63 -> ~22 -> ~8 -> ...: a
+            // handful of short rounds at the very end of the pass instead of another pass).  The idle
+            // lanes work ahead: with at most 32 (16, 8) targets left, 2 (4, 8) lanes per target try its
+            // next 2 (4, 8) candidates at once, which shortens the chain of rounds a hard target needs;
+            // the group then acts on the first candidate, in order, that is not a plain rejection.
+            lgG = held0 <= MM_DRAIN_G8 ? 3 : (held0 <= 16 ? 2 : (held0 <= 32 ? 1 : 0));
+            const int entry = lane >> lgG;
+            active = entry < held0;
+            if (active) {
+                const int2 e = my_q0[entry];
+                i = e.x;
+                j = e.y + (lane & ((1 << lgG) - 1));
+            }
+            held0 = 0;
         } else {
             break;
         }
@@ -526,7 +603,12 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
         i64 tid = i;   // the target's own index
         if (active) {
             double px, py, pz;
-            if (SORTED) {
+            if (fresh) {
+                px = cur_p[0];
+                py = cur_p[1];
+                pz = cur_p[2];
+                if (SORTED) tid = (i64)(int)__double_as_longlong(cur_p[3]);
+            } else if (SORTED) {
                 const double2 *r2 = reinterpret_cast<const double2 *>(pts + i * 4);
                 const double2 xy = r2[0], zw = r2[1];
                 px = xy.x;
@@ -546,11 +628,18 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
             // that works ahead looks at its one candidate only: outside the box = rejected)
             bool have = false;
             for (; j < k; ++j) {
-                const i64 elem = (i64)nn[i * k + j];
+                const bool from_pf = fresh && j == j0;
+                const i64 elem = from_pf ? (i64)cur_elem : (i64)nn[i * k + j];
                 const bool valid_elem = !(nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem);
                 bool outside = true;
                 if (valid_elem) {
-                    load_corners<EXODUS>(conn, nodes, elem, c);
+                    if (from_pf) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) c.id[n] = cur_id[n];
+                    } else {
+                        load_ids<EXODUS>(conn, elem, c.id);
+                    }
+                    load_xyz(nodes, c);
                     double xlo = c.x[0], xhi = c.x[0], ylo = c.y[0], yhi = c.y[0];
 #pragma unroll
                     for (int n = 1; n < 8; ++n) {
@@ -674,6 +763,10 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
             else held2 += __popcll(svote);
         }
         wave_fence();
+        if (need_b) {
+            prefetch_b();
+            need_b = false;
+        }
         MM_LSTAMP(6);   // queue appends
     }
     if (FAST && unsure_count && lane == 0 && unsure > 0) atomicAdd(unsure_count, unsure);
@@ -759,7 +852,15 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
     const typename PassFn<IDX>::type first_fn = fast ? pass_kernel_for<IDX, true>(conn_is_exodus != 0, tsorted != nullptr, nid32)
                                                      : pass_kernel_for<IDX, false>(conn_is_exodus != 0, tsorted != nullptr, nid32);
     const i64 resident = resident_workgroups(ctx, first_fn);
-    const i64 grid = resident < full_grid ? resident : full_grid;
+    i64 grid = resident < full_grid ? resident : full_grid;
+    {
+        // (tuning: MM_LOCATE_BATCHES_PER_WAVE = fewest fresh batches a wave should get before the grid is cut down)
+        static const i64 min_batches = getenv("MM_LOCATE_BATCHES_PER_WAVE") ? atoll(getenv("MM_LOCATE_BATCHES_PER_WAVE")) : 0;
+        if (min_batches > 0) {
+            const i64 want = ((npoints + 63) / 64 + min_batches * (kPassBlock / 64) - 1) / (min_batches * (kPassBlock / 64));
+            if (want < grid) grid = want < 8 ? 8 : want;
+        }
+    }
     // ONE launch over all targets.  Persistent waves: exactly as many workgroups as the device keeps
     // resident, so that every wave lives for the whole pass and its private queues see a long stream
     // of targets.

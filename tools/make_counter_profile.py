@@ -11,6 +11,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
@@ -41,7 +42,9 @@ for f in glob.glob(root + "/pass*/**/*kernel_trace.csv", recursive=True):
         if k:
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 
-res = {"_note": " ".join(__doc__.split("\n\n", 1)[1].split())}
+res = {"_note": " ".join(__doc__.split("\n\n", 1)[1].split()),
+       # the arithmetic of the hex8 locate stage the passes ran in (bench.py --fp-mode, default tol)
+       "_fp_mode": "exact" if "--fp-mode exact" in os.environ.get("MM_COUNTER_ARGS", "") else "tol"}
 for k, counters in sorted(sums.items()):
     # the largest dispatches only (the locate pass kernel is launched again on small remainders)
     e = {}
