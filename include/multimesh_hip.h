@@ -210,6 +210,19 @@ int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, int64_t nnod
                             int64_t npoints, const double *fields_d, int64_t ncomp,
                             int64_t nelem_to_search, double *out_d, int64_t *enc_d, double *w_d);
 
+/* A source mesh kept resident for repeated calls -- what the reference does when it builds its cKDTree once and queries it
+ * for each of the 125 GLL points of the target elements or for every time step (scripts/cli.py:141-195):
+ * mm_source_create computes the element centroids and the search grid ONCE; mm_interpolate_hex8_on is mm_interpolate_hex8
+ * without those two stages (results identical, bit for bit).  nodes_d / connectivity_d are BORROWED: they must stay alive
+ * and unchanged until mm_source_destroy. */
+typedef struct mm_source mm_source;
+int mm_source_create(mm_context *ctx, const double *nodes_d, int64_t nnodes, const int64_t *connectivity_d, int64_t nelem,
+                     mm_source **out);
+void mm_source_destroy(mm_context *ctx, mm_source *source);
+int64_t mm_interpolate_hex8_on(mm_context *ctx, const mm_source *source, const double *points_d, int64_t npoints,
+                               const double *fields_d, int64_t ncomp, int64_t nelem_to_search, double *out_d,
+                               int64_t *enc_d, double *w_d);
+
 /* The same path fed from HOST arrays -- what the reference's callers hold (NumPy arrays handed to
  * centroid / cKDTree / triLinearInterpolator / np.sum at scripts/cli.py:62-100): nodes f64[nnodes][3],
  * connectivity int64[nelem][8] (exodus order), points f64[npoints][3], fields f64[ncomp][nnodes], in place

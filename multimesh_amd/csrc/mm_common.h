@@ -35,7 +35,8 @@ struct mm_scratch {
     char *base = nullptr;
     size_t capacity = 0;
     size_t used = 0;
-    void *guard_piece[64] = {};   // MM_GUARD_ALLOC runs: every carve is an allocation of its own
+    void *guard_piece[256] = {};  // MM_GUARD_ALLOC runs: every carve is an allocation of its own (a query over nine density
+                                  // levels carves ~8 arrays per level on top of the shared ones)
     int guard_pieces = 0;
 };
 
@@ -110,6 +111,7 @@ struct mm_context {
         i64 npts = 0, ncells = 0;
         bool dense = false;
     } lane_hint;
+    int *abort_flags = nullptr;   // non-null during a call over a guessed grid: d_counters + kMmAbortSlot (mm_aborted)
     hipStream_t copy_stream = nullptr;   // host-array entry points: uploads run beside the kernels (created on first use)
     hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr};
 };
@@ -144,7 +146,18 @@ void mm_stage_end(mm_context *ctx, int stage);
 // ("The last workgroup of a launch finishes the reduction" was tried for the bounding box and the scans and
 // measured: on this multi-XCD part the device-scope fence every workgroup needs before it takes its ticket writes
 // its XCD's L2 back -- the centroid kernel went from 0.26 to 0.72 ms, a scan's first kernel from 5 to 80 us.)
-constexpr int kMmStatSlot = 32, kMmBoxSlot = 48;
+//   24..26 (six ints) mismatch flags of a guessed grid (mm_aborted)   2..3 scratch of small readbacks
+constexpr int kMmStatSlot = 32, kMmBoxSlot = 48, kMmAbortSlot = 24;   // (slots 0..15 are cleared by every locate stage)
+
+// A call over a GUESSED search grid (mm_interpolate_hex8): abort6 = six ints, non-zero when this call's bounding box is
+// not the one the grid was laid out from.  The kernels that would be ruinously slow on a foreign grid ask first.
+__device__ __forceinline__ bool mm_aborted(const int *__restrict__ abort6)
+{
+    if (!abort6) return false;
+    const int4 a = *reinterpret_cast<const int4 *>(abort6);
+    const int2 b = *reinterpret_cast<const int2 *>(abort6 + 4);
+    return (a.x | a.y | a.z | a.w | b.x | b.y) != 0;
+}
 
 // ---- internal launchers (device pointers, no synchronisation) -------------------------
 int mm_launch_centroid(mm_context *ctx, i64 ndim, i64 nelem, i64 nper, const i64 *conn,

@@ -327,7 +327,10 @@ void *mm_scratch_take(mm_context *ctx, size_t bytes)
 {
     if (mm_guard_alloc()) {
         if (ctx->scratch.used + mm_round256(bytes) > ctx->scratch.capacity) return nullptr;
-        if (ctx->scratch.guard_pieces >= 64) return nullptr;
+        if (ctx->scratch.guard_pieces >= (int)(sizeof(ctx->scratch.guard_piece) / sizeof(ctx->scratch.guard_piece[0]))) {
+            fprintf(stderr, "multi_mesh_hip: MM_GUARD_ALLOC: more scratch carves in one call than the guard tracks (not a pool exhaustion)\n");
+            return nullptr;
+        }
         void *p = nullptr;
         if (mm_raw_alloc(ctx->device, &p, bytes > 0 ? bytes : 16) != hipSuccess) return nullptr;
         ctx->scratch.guard_piece[ctx->scratch.guard_pieces++] = p;

@@ -111,8 +111,16 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const double *__re
 
 // out: the context's PINNED mirror of its counters -- the host reads the box after a stream synchronisation, no copy
 // dispatch; stat16 (nullable): the 16 words of the grid statistic the build accumulates next, cleared on the way.
+// guess (mm_knn_build_guessed): the box the grid of this call was laid out from; mismatch6[a] = component a of THIS call's
+// box differs from it -- the expensive kernels of a guessed call look at these six words first and return at once when
+// the grid is not theirs (mm_aborted: all sources and targets sit clamped in a few boundary cells of a foreign grid, the
+// ring searches would scan nearly every source for every target), the host runs the call again after its last wait.
+struct GuessBox {
+    double v[6];
+};
 __global__ __launch_bounds__(kBlock) void bbox_final_kernel(const double *__restrict__ partial, int nblocks,
-                                                             double *__restrict__ out, long long *__restrict__ stat16)
+                                                             double *__restrict__ out, long long *__restrict__ stat16,
+                                                             GuessBox guess = GuessBox(), int *__restrict__ mismatch6 = nullptr)
 {
     // one workgroup per component (grid 6): the threads stride over the per-block partials -- eight independent
     // loads in flight each for the fused pipeline's 2048 partials: ONE round trip (a single wave walking them took
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void bbox_final_kernel(const double *__rest
     if (threadIdx.x == 0) {
         for (int wv = 1; wv < kBlock / 64; ++wv) r = a < 3 ? fmin(r, s_part[wv]) : fmax(r, s_part[wv]);
         out[a] = r;
+        if (mismatch6) mismatch6[a] = r == guess.v[a] ? 0 : 1;   // (NaN: a mismatch)
     }
 }
 
@@ -608,8 +617,9 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(GridParams g, i64 nsr
                                                            double *__restrict__ dist_out,
                                                            const int *__restrict__ list,
                                                            const int *__restrict__ list_count, int pstride,
-                                                           int list_min)
+                                                           int list_min, const int *__restrict__ abort6 = nullptr)
 {
+    if (mm_aborted(abort6)) return;
     // list != null: only the queued targets (stragglers of the fast kernel), grid-stride
     const i64 total = list ? (i64)*list_count : npts;
     if (list && total <= list_min) return;   // short lists: knn_list_wave_kernel's
@@ -636,8 +646,10 @@ __global__ __launch_bounds__(kBlock) void knn_query_levels_kernel(LevelTable lv,
                                                                   double *__restrict__ dist_out,
                                                                   const int *__restrict__ list,
                                                                   const int *__restrict__ list_count, int keep_max,
-                                                                  i64 npts, int list_min)
+                                                                  i64 npts, int list_min,
+                                                                  const int *__restrict__ abort6 = nullptr)
 {
+    if (mm_aborted(abort6)) return;
     const i64 total = list ? (i64)*list_count : npts;   // no list: every target (long lists, k > 32)
     if (list && total <= list_min) return;   // short lists: knn_list_wave_kernel's
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -876,10 +888,11 @@ __global__ __launch_bounds__(kWave) void knn_list_wave_kernel(LevelTable lv, i64
                                                               double *__restrict__ dist_out,
                                                               const int *__restrict__ list,
                                                               const int *__restrict__ list_count, int keep_max,
-                                                              int list_max)
+                                                              int list_max, const int *__restrict__ abort6 = nullptr)
 {
     __shared__ int s_off[kWaveRuns];
     __shared__ int s_beg[kWaveRuns];
+    if (mm_aborted(abort6)) return;
     const int total = *list_count;
     if (total > list_max) return;   // long lists fill the chip one lane per target: the scalar kernels'
     for (int q = blockIdx.x; q < total; q += gridDim.x) {
@@ -2578,7 +2591,7 @@ void launch_generic(mm_context *ctx, const mm_knn_index *ix, const GridParams &g
     if (list && grid > 4096) grid = 4096;  // queue length is only known on the device: grid-stride
     hipLaunchKernelGGL((knn_query_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, g, ix->nsrc,
                        ix->cell_start, ix->sorted_xyz, pts, npts, ix->ndim, kout, idx, dist, list,
-                       list_count, pstride, list_min);
+                       list_count, pstride, list_min, (const int *)ctx->abort_flags);
 }
 
 __global__ __launch_bounds__(kBlock) void list_all_kernel(int *__restrict__ list, int *__restrict__ count, i64 n)
@@ -2611,14 +2624,15 @@ void launch_list(mm_context *ctx, const mm_knn_index *ix, const LevelTable &lv, 
         const i64 grid = cap < 8192 ? (cap > 0 ? cap : 1) : 8192;
         hipLaunchKernelGGL((knn_list_wave_kernel<(K <= 32 ? K : 32), IDX>), dim3((unsigned)grid), dim3(kWave), 0,
                            ctx->stream, lv, ix->nsrc, pts, ix->ndim, pstride, kout, idx, dist, list, list_count,
-                           keep_max, wave_max);
+                           keep_max, wave_max, (const int *)ctx->abort_flags);
     }
     if (npts <= wave_max) return;   // the list cannot be longer than the query
     i64 grid = (npts + kBlock - 1) / kBlock;
     if (grid > 4096) grid = 4096;
     if (lv.n > 1)
         hipLaunchKernelGGL((knn_query_levels_kernel<K, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, lv,
-                           ix->nsrc, pts, ix->ndim, kout, idx, dist, list, list_count, keep_max, npts, wave_max);
+                           ix->nsrc, pts, ix->ndim, kout, idx, dist, list, list_count, keep_max, npts, wave_max,
+                           (const int *)ctx->abort_flags);
     else
         launch_generic<K, IDX>(ctx, ix, lv.g[0], pts, npts, kout, idx, dist, list, list_count, pstride, wave_max);
 }
@@ -2908,9 +2922,14 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     if (rc != MM_OK) { free_index(ix); return rc; }
     const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
     if (guessed)   // this call's own box goes to the pinned mirror, where mm_knn_guess_confirmed finds it at the end of the call
-        hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, guessed->box_partial, guessed->box_nblocks,
-                           reinterpret_cast<double *>(ctx->h_counters + kBoxSlot),
-                           reinterpret_cast<long long *>(ctx->d_counters + kStatSlot));
+        {
+            GuessBox gb6;
+            for (int q = 0; q < 6; ++q) gb6.v[q] = box[q];
+            hipLaunchKernelGGL(bbox_final_kernel, dim3(6), dim3(kBlock), 0, ctx->stream, guessed->box_partial, guessed->box_nblocks,
+                               reinterpret_cast<double *>(ctx->h_counters + kBoxSlot),
+                               reinterpret_cast<long long *>(ctx->d_counters + kStatSlot), gb6,
+                               reinterpret_cast<int *>(ctx->d_counters + kMmAbortSlot));
+        }
     if (nsrc > 0)
         hipLaunchKernelGGL(cell_count_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, ndim, g, cell_of,
                            counts, (const int *)nullptr, (const int *)nullptr);

@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                                                           const double *__restrict__ pts,
                                                           unsigned long long *__restrict__ nfailed,
                                                           const int *__restrict__ list,
-                                                          const int *__restrict__ list_count, int zero_failed)
+                                                          const int *__restrict__ list_count, int zero_failed,
+                                                          const int *__restrict__ abort6 = nullptr)
 {
+    if (mm_aborted(abort6)) return;   // (a guessed grid that is not this call's: the host runs the call again)
     // list != null: only the queued targets (left over by the fast passes), grid-stride
     const i64 total = list ? (i64)*list_count : npoints;
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -379,8 +381,10 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
                                                                  const int *__restrict__ in_list,
                                                                  const int *__restrict__ in_count, int j0,
                                                                  int planes = 0, int panel = 0,
-                                                                 int *__restrict__ unsure_count = nullptr)
+                                                                 int *__restrict__ unsure_count = nullptr,
+                                                                 const int *__restrict__ abort6 = nullptr)
 {
+    if (mm_aborted(abort6)) return;   // (a guessed grid that is not this call's: the host runs the call again)
     // in_list (nullable): only the targets in_list[0 .. *in_count), each from candidate j0 on -- the second
     // pass over the targets that exhausted their lazily evaluated candidates, on their full lists (nn then holds k = the
     // full length per row; candidates before j0 were rejected by the first pass and would be rejected again).
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
 template <typename IDX>
 struct PassFn {
     typedef void (*type)(i64, i64, const IDX *, const i64 *, i64, Emit, const double *, const double *, int *, int *,
-                         const int *, const int *, int, int, int, int *);
+                         const int *, const int *, int, int, int, int *, const int *);
 };
 
 template <typename IDX, bool FAST>
@@ -872,7 +876,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         const int planes = (tsorted && lazy && lazy->index && !lazy->index->fine) ? lazy->index->dims[0] : 0;
         const int panel = panel_env;   // (0: in order, < 0: the kernel's default)
         hipLaunchKernelGGL(first_fn, g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, nodes, tsorted ? tsorted : pts,
-                           slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel, unsure_count);
+                           slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel, unsure_count,
+                           (const int *)ctx->abort_flags);
     }
     mm_stage_end(ctx, MM_STAGE_LOCATE_PASS0);
     // out of candidates without an acceptance: reference-order kernel
@@ -908,7 +913,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
                 hipLaunchKernelGGL((fast ? pass_kernel_for<IDX, true>(conn_is_exodus != 0, false, nid32b)
                                          : pass_kernel_for<IDX, false>(conn_is_exodus != 0, false, nid32b)),
                                    g_, b_, 0, ctx->stream, k_slow, npoints, nn_slow, conn, nelem, em, nodes, pts, slow2, slow2_count,
-                                   (const int *)slow, (const int *)slow_count, (int)k, 0, 0, unsure_count);
+                                   (const int *)slow, (const int *)slow_count, (int)k, 0, 0, unsure_count,
+                                   (const int *)ctx->abort_flags);
                 slow = slow2;
                 slow_count = slow2_count;
             }
@@ -918,10 +924,12 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         dim3 g((unsigned)sgrid), b(block);
         if (conn_is_exodus)
             hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
-                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed,
+                               (const int *)ctx->abort_flags);
         else
             hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
-                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed);
+                               nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed,
+                               (const int *)ctx->abort_flags);
     }
     MM_HIP_CHECK(hipGetLastError());
     static const bool dbg_locate = getenv("MM_LOCATE_DEBUG") != nullptr;

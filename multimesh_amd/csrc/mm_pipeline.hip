@@ -3,6 +3,7 @@
 // binds them; reference scripts/cli.py:62-100 is the call sequence the fused entry reproduces).
 #include <cstdlib>
 #include <mutex>
+#include <new>
 
 #include "mm_common.h"
 
@@ -51,10 +52,25 @@ static int feed_upload(mm_context *ctx, const mm_host_feed *feed, int first, int
     return MM_OK;
 }
 
+// A source mesh kept resident for repeated calls (mm_source_create): the caller's node and connectivity arrays
+// (borrowed: they must stay alive and unchanged) with the element centroids and the search grid over them, built once --
+// what the reference does when it builds its cKDTree once and queries it for every GLL point of the element / every
+// time step (scripts/cli.py:141-195).
+struct mm_source {
+    const double *nodes = nullptr;
+    i64 nnodes = 0;
+    const i64 *conn = nullptr;
+    i64 nelem = 0;
+    double *centroids = nullptr;   // owned
+    mm_knn_index *index = nullptr; // owned (its arrays are its own, not the context's buffer cache)
+    int device = 0;
+};
+
 static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int64_t nnodes,
                                      const int64_t *conn_d, int64_t nelem, const double *points_d,
                                      int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
-                                     double *out_d, int64_t *enc_d, double *w_d, const mm_host_feed *feed)
+                                     double *out_d, int64_t *enc_d, double *w_d, const mm_host_feed *feed,
+                                     const mm_source *resident = nullptr)
 {
     MM_REQUIRE(ctx != nullptr, "ctx is null");
     MM_REQUIRE(nnodes >= 1 && nelem >= 1, "empty source mesh");
@@ -93,8 +109,10 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     int *nn_full = nullptr;
     const double *tsorted = nullptr;
     mm_lazy_lists lazy;
-    rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
-    if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_BOX_PARTIAL, (size_t)kBoxBlocks * 6 * sizeof(double), (void **)&box_partial);
+    if (!resident) {
+        rc = mm_buffer_get(ctx, MM_BUF_CENTROID, (size_t)nelem * 3 * sizeof(double), (void **)&cen);
+        if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_BOX_PARTIAL, (size_t)kBoxBlocks * 6 * sizeof(double), (void **)&box_partial);
+    }
     if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_NN, (size_t)npoints * (size_t)kq * sizeof(int), (void **)&nn);
     if (rc == MM_OK && kq < k)
         rc = mm_buffer_get(ctx, MM_BUF_NN_FULL, (size_t)npoints * (size_t)k * sizeof(int), (void **)&nn_full);
@@ -126,8 +144,16 @@ static int64_t interpolate_hex8_impl(mm_context *ctx, const double *nodes_d, int
     // guess runs the call again the ordinary way (twice wrong: no more guessing in this context).  MM_GRID_GUESS=0
     // switches it off.
     static const bool guess_on = !(getenv("MM_GRID_GUESS") && atoi(getenv("MM_GRID_GUESS")) == 0);
-    guessed = guess_on && ctx->grid_guess.valid && ctx->grid_guess.nsrc == nelem && ctx->grid_guess.misses < 2;
+    // (MM_KNN_PER_CELL / MM_KNN_LEVELS are read per call by the ordinary build -- tests switch them inside one process --
+    // and a guessed build would ignore them)
+    guessed = guess_on && ctx->grid_guess.valid && ctx->grid_guess.nsrc == nelem && ctx->grid_guess.misses < 2 &&
+              !getenv("MM_KNN_PER_CELL") && !getenv("MM_KNN_LEVELS") && !resident;
 again:
+    ctx->abort_flags = nullptr;
+    if (resident) {
+        index = resident->index;   // centroids and grid are there: straight to the query
+        goto query;
+    }
     if (feed && (rc = feed_upload(ctx, feed, 0, 1, 0)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_CENTROID);
     rc = mm_launch_centroid_bbox(ctx, nelem, (const i64 *)conn_d, nodes_d, cen, box_partial, kBoxBlocks);
@@ -135,8 +161,12 @@ again:
     if (rc != MM_OK) { result = rc; goto done; }
 
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
+    ctx->abort_flags = nullptr;
     if (guessed) {
         ++ctx->grid_guess.calls_guessed;
+        // (from here to the end of the call the ring searches and the locate kernels return at once when this call's box
+        // turns out not to be the guessed one: bbox_final_kernel sets the flags on the device)
+        ctx->abort_flags = reinterpret_cast<int *>(ctx->d_counters + kMmAbortSlot);
         rc = mm_knn_build_guessed(ctx, cen, nelem, box_partial, kBoxBlocks, &index);
     } else {
         rc = mm_knn_build_impl(ctx, cen, nelem, 3, &index, true, box_partial, kBoxBlocks);
@@ -144,6 +174,7 @@ again:
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     if (rc != MM_OK) { result = rc; goto done; }
 
+query:
     if (feed && (rc = feed_upload(ctx, feed, 2, 2, 1)) != MM_OK) { result = rc; goto done; }
     mm_stage_begin(ctx, MM_STAGE_KNN_QUERY);
     // (the candidate rows come back in the cell-sorted order of the targets whenever the lane kernel serves the
@@ -183,6 +214,7 @@ again:
         ctx->grid_guess.valid = false;
         ++ctx->grid_guess.misses;
         guessed = false;
+        ctx->abort_flags = nullptr;
         mm_knn_destroy(nullptr, index);
         index = nullptr;
         feed = nullptr;   // (the device copies of host arrays are in place)
@@ -190,10 +222,13 @@ again:
         goto again;
     }
     result = ctx->h_counters[0];
+    // (a long-lived context forgives old misses: every 64 calls that confirmed their guess take one back)
+    if (guessed && ctx->grid_guess.misses > 0 && (ctx->grid_guess.calls_guessed & 63) == 0) --ctx->grid_guess.misses;
 
 done:
+    ctx->abort_flags = nullptr;
     if (result < 0) (void)hipStreamSynchronize(ctx->stream);
-    if (index) mm_knn_destroy(nullptr, index);  // borrowed arrays stay in the context cache
+    if (index && !resident) mm_knn_destroy(nullptr, index);  // borrowed arrays stay in the context cache
     return result;
 #undef MM_PIPE_FAIL
 }
@@ -217,6 +252,73 @@ extern "C" int64_t mm_interpolate_hex8(mm_context *ctx, const double *nodes_d, i
 {
     return interpolate_hex8_impl(ctx, nodes_d, nnodes, conn_d, nelem, points_d, npoints, fields_d, ncomp, k, out_d,
                                  enc_d, w_d, nullptr);
+}
+
+extern "C" int mm_source_create(mm_context *ctx, const double *nodes_d, int64_t nnodes, const int64_t *conn_d, int64_t nelem,
+                                mm_source **out)
+{
+    MM_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+    *out = nullptr;
+    MM_REQUIRE(nnodes >= 1 && nelem >= 1 && nelem < (int64_t)0x7fffffff, "bad mesh size");
+    MM_REQUIRE(nodes_d && conn_d, "null mesh array");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    mm_source *s = new (std::nothrow) mm_source();
+    if (!s) {
+        mm_set_error(MM_ERR_ALLOC, "out of host memory");
+        return MM_ERR_ALLOC;
+    }
+    s->nodes = nodes_d;
+    s->nnodes = nnodes;
+    s->conn = (const i64 *)conn_d;
+    s->nelem = nelem;
+    s->device = ctx->device;
+    int rc = MM_OK;
+    if (mm_raw_alloc(ctx->device, (void **)&s->centroids, (size_t)nelem * 3 * sizeof(double)) != hipSuccess) {
+        mm_set_error(MM_ERR_ALLOC, "mm_source_create: device allocation failed");
+        rc = MM_ERR_ALLOC;
+    }
+    mm_stage_reset(ctx);
+    if (rc == MM_OK) {
+        mm_stage_begin(ctx, MM_STAGE_CENTROID);
+        rc = mm_launch_centroid(ctx, 3, nelem, 8, (const i64 *)conn_d, nodes_d, s->centroids);
+        mm_stage_end(ctx, MM_STAGE_CENTROID);
+    }
+    if (rc == MM_OK) {
+        mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
+        rc = mm_knn_build_impl(ctx, s->centroids, nelem, 3, &s->index, /*use_context_buffers=*/false, nullptr, 0);
+        mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
+    }
+    if (rc == MM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "mm_source_create: synchronise failed");
+        rc = MM_ERR_HIP;
+    }
+    if (rc != MM_OK) {
+        if (s->index) mm_knn_destroy(nullptr, s->index);
+        if (s->centroids) (void)mm_raw_free(s->centroids);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return MM_OK;
+}
+
+extern "C" void mm_source_destroy(mm_context *ctx, mm_source *source)
+{
+    if (!source) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (source->index) mm_knn_destroy(nullptr, source->index);
+    if (source->centroids) (void)mm_raw_free(source->centroids);
+    delete source;
+}
+
+extern "C" int64_t mm_interpolate_hex8_on(mm_context *ctx, const mm_source *source, const double *points_d,
+                                          int64_t npoints, const double *fields_d, int64_t ncomp, int64_t k,
+                                          double *out_d, int64_t *enc_d, double *w_d)
+{
+    MM_REQUIRE(ctx != nullptr && source != nullptr, "null argument");
+    MM_REQUIRE(source->device == ctx->device, "the source lives on another device");
+    return interpolate_hex8_impl(ctx, source->nodes, source->nnodes, (const int64_t *)source->conn, source->nelem, points_d,
+                                 npoints, fields_d, ncomp, k, out_d, enc_d, w_d, nullptr, source);
 }
 
 // The same path fed from HOST arrays (what the reference's callers hold: NumPy arrays, scripts/cli.py:62-100):
@@ -299,13 +401,53 @@ static mm_context *legacy_context()
 }
 
 namespace {
-template <typename T>
-i64 max_plus_one(const T *a, size_t n)
+// Smallest and largest entry of an index array that is already on the device: the reference's signatures do not
+// carry the element and node counts, which are recovered as max + 1.  (Round 3 scanned the HOST arrays: ~1 ns per
+// entry on one core, 0.9 of the 1.36 ms a warm triLinearInterpolator call took for 20 k points on a 64 k-element mesh
+// -- reference scripts/cli.py:183-195 makes 125 such calls in a row.)
+__global__ __launch_bounds__(256) void minmax_init_kernel(long long *out2)
 {
-    T m = -1;
-    for (size_t i = 0; i < n; ++i)
-        if (a[i] > m) m = a[i];
-    return (i64)m + 1;
+    if (threadIdx.x == 0) {
+        out2[0] = 0x7fffffffffffffffll;
+        out2[1] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_i64_kernel(const i64 *__restrict__ a, size_t n, long long *__restrict__ out2)
+{
+    i64 lo = 0x7fffffffffffffffll, hi = -1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const i64 v = a[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const i64 l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out2, lo);
+        atomicMax(out2 + 1, hi);
+    }
+}
+
+// lo / hi of a device array (synchronises the context's stream)
+int device_minmax(mm_context *ctx, const i64 *a_d, size_t n, i64 *lo, i64 *hi)
+{
+    long long *slot = (long long *)(ctx->d_counters + 2);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, ctx->stream, slot);
+    if (n > 0) {
+        size_t grid = (n + 256 * 8 - 1) / (256 * 8);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(minmax_i64_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a_d, n, slot);
+    }
+    MM_HIP_CHECK(hipGetLastError());
+    MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 2, slot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *lo = ctx->h_counters[2];
+    *hi = ctx->h_counters[3];
+    return MM_OK;
 }
 }  // namespace
 
@@ -332,16 +474,30 @@ extern "C" void centroid(long long ndim, long long nelem, long long nper, long l
         return;
     }
     const size_t nconn = (size_t)nelem * (size_t)nper;
-    const i64 npoints = max_plus_one(connectivity, nconn);
     // device copies from the context's grow-only cache (no hipMalloc / hipFree per call)
     void *d_conn = nullptr, *d_pts = nullptr, *d_out = nullptr;
     if (mm_buffer_get(ctx, MM_BUF_L_CONN, nconn * sizeof(i64), &d_conn) != MM_OK ||
-        mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)npoints * ndim * sizeof(double), &d_pts) != MM_OK ||
         mm_buffer_get(ctx, MM_BUF_L_W, (size_t)nelem * ndim * sizeof(double), &d_out) != MM_OK) {
         (void)legacy_fail("centroid");
         return;
     }
     hipError_t e = hipMemcpyAsync(d_conn, connectivity, nconn * sizeof(i64), hipMemcpyHostToDevice, ctx->stream);
+    // the number of points the signature does not carry: largest node id + 1, found on the device
+    i64 id_lo = 0, id_hi = -1;
+    if (e == hipSuccess && device_minmax(ctx, (const i64 *)d_conn, nconn, &id_lo, &id_hi) != MM_OK) {
+        (void)legacy_fail("centroid");
+        return;
+    }
+    if (e == hipSuccess && id_lo < 0) {
+        mm_set_error(MM_ERR_ARG, "centroid: negative node id");
+        (void)legacy_fail("centroid");
+        return;
+    }
+    const i64 npoints = id_hi + 1;
+    if (e == hipSuccess && mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)npoints * ndim * sizeof(double), &d_pts) != MM_OK) {
+        (void)legacy_fail("centroid");
+        return;
+    }
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_pts, points, (size_t)npoints * ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
@@ -373,31 +529,39 @@ extern "C" long long triLinearInterpolator(long long k, long long npoints, long 
     }
     mm_context *ctx = legacy_context();
     if (!ctx) return legacy_fail("triLinearInterpolator");
-    // sizes the reference signature does not carry
+    // sizes the reference signature does not carry: largest index + 1, found on the DEVICE after the upload
     const size_t nnn = (size_t)npoints * (size_t)k;
-    for (size_t i = 0; i < nnn; ++i)
-        if (nn[i] < 0) {
-            mm_set_error(MM_ERR_ARG, "triLinearInterpolator: negative element index");
-            return legacy_fail("triLinearInterpolator");
-        }
-    const i64 nelem = max_plus_one(nn, nnn);
-    const i64 nnodes = max_plus_one(connectivity, (size_t)nelem * 8);
     // device copies from the context's grow-only cache: the reference's exodus_2_gll flow calls this symbol once per
     // GLL point of the element (scripts/cli.py:183-195: 125 calls on the same mesh), and six hipMalloc / hipFree pairs
     // of mesh-sized buffers per call cost more than the kernels
     void *d_nn = nullptr, *d_conn = nullptr, *d_enc = nullptr, *d_nodes = nullptr, *d_w = nullptr, *d_pts = nullptr;
     if (mm_buffer_get(ctx, MM_BUF_L_NN, nnn * sizeof(i64), &d_nn) != MM_OK ||
-        mm_buffer_get(ctx, MM_BUF_L_CONN, (size_t)nelem * 8 * sizeof(i64), &d_conn) != MM_OK ||
         mm_buffer_get(ctx, MM_BUF_L_ENC, (size_t)npoints * 8 * sizeof(i64), &d_enc) != MM_OK ||
-        mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)nnodes * 3 * sizeof(double), &d_nodes) != MM_OK ||
         mm_buffer_get(ctx, MM_BUF_L_W, (size_t)npoints * 8 * sizeof(double), &d_w) != MM_OK ||
         mm_buffer_get(ctx, MM_BUF_L_PTS, (size_t)npoints * 3 * sizeof(double), &d_pts) != MM_OK)
         return legacy_fail("triLinearInterpolator");
     hipStream_t s = ctx->stream;
     hipError_t e = hipMemcpyAsync(d_nn, nn, nnn * sizeof(i64), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_conn, connectivity, (size_t)nelem * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, nodes, (size_t)nnodes * 3 * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_pts, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    i64 lo = 0, hi = -1;
+    if (e == hipSuccess && device_minmax(ctx, (const i64 *)d_nn, nnn, &lo, &hi) != MM_OK) return legacy_fail("triLinearInterpolator");
+    if (e == hipSuccess && lo < 0) {
+        mm_set_error(MM_ERR_ARG, "triLinearInterpolator: negative element index");
+        return legacy_fail("triLinearInterpolator");
+    }
+    const i64 nelem = hi + 1;
+    if (e == hipSuccess && mm_buffer_get(ctx, MM_BUF_L_CONN, (size_t)nelem * 8 * sizeof(i64), &d_conn) != MM_OK)
+        return legacy_fail("triLinearInterpolator");
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conn, connectivity, (size_t)nelem * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && device_minmax(ctx, (const i64 *)d_conn, (size_t)nelem * 8, &lo, &hi) != MM_OK) return legacy_fail("triLinearInterpolator");
+    if (e == hipSuccess && lo < 0) {
+        mm_set_error(MM_ERR_ARG, "triLinearInterpolator: negative node id");
+        return legacy_fail("triLinearInterpolator");
+    }
+    const i64 nnodes = hi + 1;
+    if (e == hipSuccess && mm_buffer_get(ctx, MM_BUF_L_NODES, (size_t)nnodes * 3 * sizeof(double), &d_nodes) != MM_OK)
+        return legacy_fail("triLinearInterpolator");
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, nodes, (size_t)nnodes * 3 * sizeof(double), hipMemcpyHostToDevice, s);
     // in-place contract: rows of failed points keep the caller's contents
     if (e == hipSuccess) e = hipMemcpyAsync(d_enc, enc, (size_t)npoints * 8 * sizeof(i64), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_w, weights, (size_t)npoints * 8 * sizeof(double), hipMemcpyHostToDevice, s);

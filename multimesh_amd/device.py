@@ -100,6 +100,45 @@ class KnnIndex:
             pass
 
 
+class Source:
+    """A hex8 source mesh kept resident for repeated calls (mm_source_create): nodes, connectivity, element centroids and
+    the search grid over them -- built once, like the reference's cKDTree (scripts/cli.py:66, queried at :141-195)."""
+
+    def __init__(self, ctx, handle, nodes, conn):
+        self.ctx, self.handle = ctx, handle
+        self.nodes, self.conn = nodes, conn      # (borrowed by the library: kept alive here)
+
+    def interpolate(self, points, fields, nelem_to_search=20, want_operator=False, out=None):
+        """:meth:`Context.interpolate_hex8` without the centroid and grid-build stages; identical results."""
+        ctx = self.ctx
+        pts = ctx.asdevice(points, np.float64)
+        f = ctx.asdevice(fields, np.float64)
+        if len(f.shape) == 1:
+            f = DeviceArray(ctx, f.ptr, (1, f.shape[0]), f.dtype, owner=False, keepalive=f)
+        if f.shape[1] != self.nodes.shape[0]:
+            raise ValueError("fields must be [C, number of nodes]")
+        n, ncomp = pts.shape[0], f.shape[0]
+        out = ctx.empty((n, ncomp), np.float64) if out is None else ctx.asdevice(out, np.float64)
+        enc = ctx.empty((n, 8), np.int64) if want_operator else None
+        w = ctx.empty((n, 8), np.float64) if want_operator else None
+        nf = check(ctx.lib.mm_interpolate_hex8_on(ctx.handle, self.handle, pts.ptr, n, f.ptr, ncomp, nelem_to_search, out.ptr,
+                                                  enc.ptr if enc else None, w.ptr if w else None), "mm_interpolate_hex8_on")
+        if want_operator:
+            return out, enc, w, int(nf)
+        return out, int(nf)
+
+    def free(self):
+        if self.handle and self.ctx.handle:
+            self.ctx.lib.mm_source_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU + one HIP stream.  ``stream`` is a raw hipStream_t value (e.g.
     ``torch.cuda.current_stream().cuda_stream``); None = the device's default stream."""
@@ -356,6 +395,14 @@ class Context:
         if want_operator:
             return out, enc, w, int(nf)
         return out, int(nf)
+
+    def source(self, nodes, connectivity):
+        """Keep a hex8 source mesh resident (centroids + search grid built once): :class:`Source`."""
+        nod = self.asdevice(nodes, np.float64)
+        conn = self.asdevice(connectivity, np.int64)
+        h = C.c_void_p()
+        check(self.lib.mm_source_create(self.handle, nod.ptr, nod.shape[0], conn.ptr, conn.shape[0], C.byref(h)), "mm_source_create")
+        return Source(self, h.value, nod, conn)
 
     def interpolate_hex8_host(self, nodes, connectivity, points, fields, nelem_to_search=20, want_operator=False,
                               out=None):

@@ -119,3 +119,48 @@ def test_switch_off():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.timeout(300)
+def test_a_miss_at_a_realistic_size_is_cheap():
+    # ADVICE (round 3): a guessed grid from a mesh of the same element count in ANOTHER place clamps every source and
+    # target into a few boundary cells; without a device-side check the ring searches then scan nearly all sources for
+    # every target (1M x 1M here: minutes, and it looks like a hang) before the host notices.  bbox_final_kernel now
+    # compares this call's box with the guess on the device and the ring-search and locate kernels return at once: the
+    # miss costs one cheap extra pass.  1M -> 1M, the second mesh shifted and scaled; bit-equal to a fresh context and
+    # within a few times the time of an ordinary call.
+    import time
+
+    from multimesh_amd.device import Context
+
+    pa, ca = synth.hex_mesh(101, seed=1)
+    pb, _ = synth.hex_mesh(101, seed=7)
+    f = synth.vector_field(pa)[:1]
+    pa2, pb2 = pa * 3.0 + 10.0, pb * 3.0 + 10.0
+    f2 = synth.vector_field(pa2)[:1]
+    c = Context(0)
+    try:
+        d = [c.to_device(x) for x in (pa, ca, pb, f, pa2, pb2, f2)]
+        c.interpolate_hex8(d[0], d[1], d[2], d[3])                      # leaves mesh A's box as the guess
+        c.interpolate_hex8(d[0], d[1], d[2], d[3])                      # a guessed call that is confirmed
+        c.synchronize()
+        t0 = time.perf_counter()
+        c.interpolate_hex8(d[0], d[1], d[2], d[3])
+        c.synchronize()
+        t_hit = time.perf_counter() - t0
+        before = _guess_state(c)
+        t0 = time.perf_counter()
+        v2, nf2 = c.interpolate_hex8(d[4], d[1], d[5], d[6])            # same element count, another box: a miss
+        c.synchronize()
+        t_miss = time.perf_counter() - t0
+        after = _guess_state(c)
+        assert after["misses"] == before["misses"] + 1 and after["guessed"] == before["guessed"] + 1
+        assert t_miss < max(30 * t_hit, 0.5), (t_hit, t_miss)           # (an unguarded miss: tens of seconds)
+        fresh = Context(0)
+        try:
+            v_ref, nf_ref = fresh.interpolate_hex8(pa2, ca, pb2, f2)
+            assert nf2 == nf_ref == 0 and np.array_equal(v2.numpy(), v_ref.numpy())
+        finally:
+            fresh.close()
+    finally:
+        c.close()

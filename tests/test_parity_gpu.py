@@ -890,3 +890,37 @@ def test_stage_timers_levels(ctx):
     finally:
         ctx.set_profiling(False)
     assert np.array_equal(got[True], got[2]) and np.array_equal(got[True], got[False])
+
+
+# ------------------------------------------------------------------------------- resident source
+def test_resident_source_gives_the_fused_path_bit_for_bit(ctx, golden):
+    # mm_source_create builds centroids + search grid once (the reference builds its cKDTree once and queries it for
+    # every GLL point / time step, scripts/cli.py:141-195); mm_interpolate_hex8_on is the fused path without those two
+    # stages.  Same bits as mm_interpolate_hex8 and as the reference fixtures, call after call, lazy and eager lists.
+    d = golden("hex8_hard_k20")
+    src = ctx.source(d["points_a"], d["conn_a"])
+    try:
+        for lazy in (True, False, True):
+            ctx.set_lazy_lists(lazy)
+            try:
+                vals, enc, w, nf = src.interpolate(d["points_b"], d["fields"], nelem_to_search=int(d["k"]), want_operator=True)
+                vals2, nf2 = src.interpolate(d["points_b"], d["fields"], nelem_to_search=int(d["k"]))
+            finally:
+                ctx.set_lazy_lists(True)
+            assert nf == nf2 == int(d["nfailed"])
+            assert np.array_equal(enc.numpy(), d["enc"]) and np.array_equal(w.numpy(), d["w"])
+            assert vals.numpy().tobytes() == np.ascontiguousarray(d["values"]).tobytes() == vals2.numpy().tobytes()
+    finally:
+        src.free()
+    # a larger mesh, many target sets against one source (and the fused path with its own rebuild in between)
+    pa, ca = synth.hex_mesh(40, seed=1)
+    fields = synth.vector_field(pa)[:2]
+    src = ctx.source(pa, ca)
+    try:
+        for seed in (7, 8, 9):
+            pb, _ = synth.hex_mesh(37 + seed, seed=seed)
+            a, nfa = src.interpolate(pb, fields)
+            b, nfb = ctx.interpolate_hex8(pa, ca, pb, fields)
+            assert nfa == nfb == 0 and np.array_equal(a.numpy(), b.numpy())
+    finally:
+        src.free()

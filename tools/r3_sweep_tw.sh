@@ -1,3 +1,5 @@
+#!/bin/bash
+# (GPU box) sweep of the lane kernel window parameters T / W on the metric workload (round 3 tuning)
 mkdir -p gpurun_out/r3
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3/pytest_a.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r3/pytest_a.log
 tail -3 gpurun_out/r3/pytest_a.log
