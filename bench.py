@@ -697,6 +697,27 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
                               "timed region (single rank, no collective)"}
         ctx.set_fp_mode(args.fp_mode)
         del o_out
+    # ... and the same step with the source mesh kept resident (mm_source_create: centroids + search grid built once,
+    # the reference's "one cKDTree, many queries", scripts/cli.py:141-195).  NOT `value`: the metric's step rebuilds.
+    resident_source = None
+    if rank == 0 and not as_rank:
+        src = ctx.source(t_nodes, t_conn)
+        r_out = torch.zeros((chunk, ncomp), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            src.interpolate(t_pts, t_fields, nelem_to_search=k, out=r_out[:n_local])
+        torch.cuda.synchronize()
+        r_steps = 5
+        t0 = time.perf_counter()
+        for _ in range(r_steps):
+            src.interpolate(t_pts, t_fields, nelem_to_search=k, out=r_out[:n_local])
+        torch.cuda.synchronize()
+        r_ms = (time.perf_counter() - t0) / r_steps * 1e3
+        resident_source = {"ms_per_call": round(r_ms, 4), "points_per_s": n_local / (r_ms * 1e-3), "calls": r_steps,
+                           "equals_the_rebuilding_step": bool(torch.equal(r_out[:n_local], t_out[:n_local])),
+                           "note": "mm_interpolate_hex8_on over a source made resident once by mm_source_create (kNN query + "
+                                   "locate + gather per call); never `value`"}
+        src.free()
+        del r_out
 
     # ---- the collective by itself: a BLOCKING all-gather, timed on the stream; then the WHOLE gathered field
     # against what one rank computes alone ----
@@ -852,6 +873,7 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
             "roofline_end_to_end": {"algorithmic_bytes_per_target": e2e_bytes,
                                     "achieved_GBps_per_gpu": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "resident_source": resident_source,
             "replicated_per_rank": {"ms": round(replicated_ms, 4), "share_of_step": round(replicated_ms / ms_per_step, 4),
                                     "note": "centroids + search-grid build of the replicated source mesh run on every rank "
                                             "whatever its share of the targets: the Amdahl term of strong scaling "
@@ -969,7 +991,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
     t_en = torch.from_numpy(tgt_en).to(dev)
     t_fields = torch.from_numpy(fields).to(dev)
     # the unique set once, to size the buffers (the timed steps recompute it into caller-owned buffers)
-    d_u, d_inv = ctx.unique_points(t_en)
+    d_u, d_inv = ctx.unique_points(t_en, ordered=False)
     t_ubuf = torch.empty(tgt_en.shape, dtype=torch.float64, device=dev)
     t_ibuf = torch.empty((tgt_en.shape[0],), dtype=torch.int64, device=dev)
     n_unique = d_u.shape[0]
@@ -994,7 +1016,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
             st["pending"][b].wait()
             st["pending"][b] = None
         ev0.record()
-        u, inv = ctx.unique_points(t_en, unique_out=t_ubuf, inverse_out=t_ibuf)   # A11 on the device
+        u, inv = ctx.unique_points(t_en, unique_out=t_ubuf, inverse_out=t_ibuf, ordered=False)   # A11 on the device (order-free form)
         ev1.record()
         _, miss = ctx.interpolate_gll(order, t_src, u.rows(lo, hi), t_fields, nelem_to_search=k, tolerance=1.05,
                                       out=outs[b][:n_local])
@@ -1088,7 +1110,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
                                                    key=["locate_gll_first_pass_kernel", "locate_gll_pass_kernel"], run_steps=3,
                                                    kernel="locate_gll_first_pass_kernel<4, 3, int> + locate_gll_pass_kernel<4, 3, int>")},
             "stages": {"unique_points": {"ms": round(st["unique_ms"] / steps, 4),
-                                         "note": "mm_unique_points over all element-nodal target points (replicated on every rank)"},
+                                         "note": "mm_unique_points_any_order (hash table; the unique rows are only interpolated and scattered back) over all element-nodal target points (replicated on every rank)"},
                        **{s: {"ms": round(v, 4)} for s, v in sm.items() if v > 0}},
         }
         if allgather:

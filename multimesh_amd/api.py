@@ -25,6 +25,7 @@ import time
 import numpy as np
 
 from .device import default_context
+from .helpers import check
 from .mesh import HexMesh
 
 TTI_PARAMS = ["VSH", "VSV", "VPV", "VPH", "RHO", "ETA", "QKAPPA", "QMU"]  # reference cli.py:58-59
@@ -234,7 +235,8 @@ def interpolate_gll_to_gll(mesh_a: GllMesh, target_gll_points, params_to_interp,
     interpolator.py:823).  ``target_gll_points`` f64[E_t, P_t, dim] -> f64[C, E_t, P_t]."""
     ctx = context or default_context()
     tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
-    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]))
+    # (the unique rows are only interpolated and scattered back: their order never reaches the result)
+    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]), ordered=False)
     fields = np.stack([mesh_a.element_nodal_fields[p] for p in params_to_interp])
     vals, num_failed = ctx.interpolate_gll(mesh_a.shape_order, mesh_a.gll_points, uniq, fields,
                                            nelem_to_search=nelem_to_search, tolerance=tolerance)
@@ -255,7 +257,7 @@ def interpolate_hex8_to_gll(mesh_a: HexMesh, target_gll_points, params, nelem_to
     that are not found get zero."""
     ctx = context or default_context()
     tgt = np.ascontiguousarray(target_gll_points, dtype=np.float64)
-    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]))
+    uniq, inv = ctx.unique_points(tgt.reshape(-1, tgt.shape[-1]), ordered=False)
     vals, nfailed = ctx.interpolate_hex8(mesh_a.points, mesh_a.connectivity, uniq, mesh_a.fields_matrix(list(params)),
                                          nelem_to_search=nelem_to_search)
     if nfailed > 0:
@@ -501,7 +503,8 @@ def _gll_operator_over_all_points(ctx, gll_points, points, nelem_to_search, igno
     tree = ctx.knn_build(gll_points.reshape(nelem * P, dim))
     pts = ctx.asdevice(points if hasattr(points, "numpy") else np.ascontiguousarray(points, dtype=np.float64),
                        np.float64)
-    nearest = np.floor(tree.query(pts, nelem_to_search).numpy() / P).astype(np.int64)
+    nearest = tree.query(pts, nelem_to_search)
+    check(ctx.lib.mm_points_to_elements(ctx.handle, nearest.ptr, nearest.size, P), "mm_points_to_elements")   # floor(index / P), on the device
     elem, coeffs, hard = ctx.locate_gll_bbox(gll_order, nearest, gll_points, pts)
     if hard and not ignore_hard_elements:
         raise ValueError("Can't find an appropriate element.")

@@ -48,7 +48,30 @@ __global__ __launch_bounds__(64) void fluid_solid_fix_kernel(double *__restrict_
     if (lane == 0 && is_solid) atomicAdd(restored, 1ull);
 }
 
+// index of a GLL point -> index of its element: floor(index / P) (reference interpolator.py:113, :777), in place
+__global__ __launch_bounds__(256) void points_to_elements_kernel(i64 *__restrict__ idx, i64 n, i64 P)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const i64 v = idx[i];
+        idx[i] = v >= 0 ? v / P : -((-v + P - 1) / P);   // floor, like np.floor(idx / P)
+    }
+}
+
 }  // namespace
+
+extern "C" int mm_points_to_elements(mm_context *ctx, int64_t *idx_d, int64_t n, int64_t P)
+{
+    MM_REQUIRE(ctx != nullptr, "ctx is null");
+    MM_REQUIRE(n >= 0 && P >= 1, "bad size");
+    if (n == 0) return MM_OK;
+    MM_REQUIRE(idx_d != nullptr, "null array");
+    MM_REQUIRE((n + 255) / 256 < (i64)0x7fffffff, "too many indices for one launch");
+    MM_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(points_to_elements_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (i64 *)idx_d, n, P);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
 
 extern "C" int mm_scatter_elements(mm_context *ctx, const double *values_d, int64_t nunique, int64_t ncomp,
                                    const int64_t *inverse_d, const int64_t *elem_ids_d, int64_t nmasked, int64_t P,

@@ -93,12 +93,26 @@ __device__ __forceinline__ void lagrange_1d(const double (&g)[ORDER + 1], double
 #define MM_GLL_FENCE_EVERY 2
 #endif
 #define MM_GLL_ROW_FENCE(row) do { if ((row) % MM_GLL_FENCE_EVERY == 0) asm volatile("" ::: "memory"); } while (0)
+// ... and the running sums pinned there as well (round 4): a memory fence keeps the LOADS of a row behind it but not
+// their consumption -- the scheduler still parks every loaded value in a register and folds them in at the end.
+template <int N>
+__device__ __forceinline__ void gll_pin(double (&v)[N])
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q) asm volatile("" : "+v"(v[q])::"memory");
+}
 // Waves per SIMD the register allocator must leave room for in the GLL locate kernels.  1: it takes what the kernel
 // needs -- at order 4 in 3-D 256 VGPRs + ~90 AGPRs, one wave per SIMD, nothing in scratch memory -- and the lower orders
 // still run 2 to 5 waves (95 - 211 VGPRs).  Asking for 3 (168 VGPRs, rounds 1 - 2) left 340 registers of the order-4
 // kernels in scratch: cfg5's locate stage 6.2 ms at 3, 5.5 at 2 (150 spilled), 5.1 at 1.
 #ifndef MM_GLL_WAVES
 #define MM_GLL_WAVES 1
+#endif
+#ifndef MM_GLL_PIN_SUMS   // 1: the partial sums of the map are pinned at every row of nodes (see gll_pin)
+#define MM_GLL_PIN_SUMS 1
+#endif
+#ifndef MM_GLL_VALUES_WAVES   // waves per SIMD gll_values_kernel is compiled for
+#define MM_GLL_VALUES_WAVES 2
 #endif
 #ifndef MM_GLL_GUESS_TRIPS   // (tuning builds only: the oracle's start runs 8)
 #define MM_GLL_GUESS_TRIPS 8
@@ -169,6 +183,12 @@ struct Gll {
                         // keep the scheduler from hoisting all (order+1)^3 node loads to the top of
                         // the unrolled loop: one row of nodes at a time
                         MM_GLL_ROW_FENCE(j);
+                        if (MM_GLL_PIN_SUMS) {
+                            gll_pin(b00);
+                            gll_pin(b01);
+                            gll_pin(b10);
+                            gll_pin(x);
+                        }
                         double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                         for (int i = 0; i < n; ++i) {
@@ -286,24 +306,41 @@ struct Gll {
     // coefficients() forms it -- or 0.0 for a point that was not found (`zero`).  One lane, all P
     // terms: the values-only pipeline uses this at the point of acceptance instead of writing the
     // P coefficients (1 kB per target at order 4) for a gather kernel to read back.
+    // LEAN (gll_values_kernel): the innermost 1-D values are made opaque at every row, so that the row's coefficient
+    // products cannot be formed before it -- left alone the scheduler forms all P of them first (250 registers at
+    // order 4 in 3-D: one wave per SIMD)
+    template <bool LEAN = false>
     static __device__ __forceinline__ double weighted_sum(const double (&l)[DIM][n], bool zero,
                                                           const double *__restrict__ f)
     {
         constexpr int tail = P & 7, nfull = P - tail;
-        double r[8];
+        double r[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
         double res = 0.;
         constexpr int nk = DIM == 3 ? n : 1;
+        double m[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) m[i] = l[0][i];
 #pragma unroll
         for (int k = 0; k < nk; ++k)
 #pragma unroll
             for (int j = 0; j < n; ++j) {
                 // one row of field values at a time (see inverse_transform): hoisting all P loads
                 // to the top of the unrolled loop spills
-                MM_GLL_ROW_FENCE(j);
+                if (LEAN) {
+                    // (... and the running sums are pinned at every row: without that the scheduler keeps every loaded
+                    // field value in a register and adds them all up at the end)
+#pragma unroll
+                    for (int i = 0; i < n; ++i) asm volatile("" : "+v"(m[i])::"memory");
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(r[q])::"memory");
+                    asm volatile("" : "+v"(res)::"memory");
+                } else {
+                    MM_GLL_ROW_FENCE(j);
+                }
 #pragma unroll
                 for (int i = 0; i < n; ++i) {
                     const int p = i + n * (j + n * k);
-                    double c = DIM == 3 ? (l[0][i] * l[1][j]) * l[DIM - 1][k] : l[0][i] * l[1][j];
+                    double c = DIM == 3 ? (m[i] * l[1][j]) * l[DIM - 1][k] : m[i] * l[1][j];
                     if (zero) c = 0.0;
                     const double a = c * f[p];
                     if (P < 8) {
@@ -330,12 +367,24 @@ struct GllEmit {
     const double *fields;  // [ncomp][nelem][P] or null
     double *out;           // [N][ncomp] or null
     int ncomp;
+    // Deferred values (round 4): with xi_defer the locate kernels only leave {element or -1, reference coordinates}
+    // per target and gll_values_kernel forms the weighted sums afterwards -- the same arithmetic in a kernel of its
+    // own.  Inside the order-4 locate kernels the unrolled 125-term sum cost 1.4 of the stage's 4.4 ms at cfg5's
+    // shape and, worse, registers: those kernels run ONE wave per SIMD (256 VGPRs + ~120 AGPRs).
+    double *xi_defer = nullptr;   // [N][DIM] or null
+    int *elem_defer = nullptr;    // [N]
 };
 
 // found == false: the reference's "-1 and zero coefficients"; NumPy's field[-1] is the LAST element
-template <int ORDER, int DIM>
+template <int ORDER, int DIM, bool DEFER = false>
 __device__ __forceinline__ void gll_emit(const GllEmit &em, i64 i, i64 e, const double (&xi)[DIM], bool found, i64 nelem)
 {
+    if (DEFER) {   // (compile-time: the instance carries neither the coefficient products nor the sums)
+        em.elem_defer[i] = found ? (int)e : -1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) em.xi_defer[i * DIM + d] = found ? xi[d] : 0.0;
+        return;
+    }
     using G = Gll<ORDER, DIM>;
     constexpr int P = G::P;
     if (em.elem) em.elem[i] = found ? e : -1;
@@ -356,6 +405,35 @@ __device__ __forceinline__ void gll_emit(const GllEmit &em, i64 i, i64 e, const 
     }
 }
 
+// The deferred half of gll_emit (GllEmit::xi_defer): out[i][c] = sum_p coeff_p(xi_i) * field[c][elem_i][p], the
+// coefficients and the sum formed exactly as there (NumPy's row-sum order; a target that was not found reads the LAST
+// element with zero coefficients like NumPy's field[-1] * 0).  One lane per target; neighbouring targets lie in the same
+// or neighbouring elements, so a wave's loads of a field row fall on a few lines.
+template <int ORDER, int DIM>
+__global__ __launch_bounds__(256, MM_GLL_VALUES_WAVES) void gll_values_kernel(i64 npoints, const int *__restrict__ elem,
+                                                         const double *__restrict__ xi_all,
+                                                         const double *__restrict__ fields, i64 nelem, int ncomp,
+                                                         double *__restrict__ out)
+{
+    using G = Gll<ORDER, DIM>;
+    constexpr int P = G::P;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    const int e = elem[i];
+    const bool found = e >= 0;
+    double g[G::n];
+    gll_nodes<ORDER>(g);
+    double l[DIM][G::n], dl[DIM][G::n];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) lagrange_1d<ORDER>(g, found ? xi_all[i * DIM + d] : 0.0, l[d], dl[d]);
+    const i64 ef = found ? (i64)e : nelem - 1;
+    for (int c = 0; c < ncomp; ++c) {
+        // (the 125 coefficient products do not depend on c: left alone, the compiler forms them all in front of this loop
+        // and keeps them in 250 registers -- one wave per SIMD; weighted_sum<LEAN> forms them row by row)
+        out[i * ncomp + c] = G::template weighted_sum<true>(l, !found, fields + ((i64)c * nelem + ef) * P);
+    }
+}
+
 // Control flow of reference interpolator.py:1181-1233 (see the oracle's mmo_locate_gll), scheduled
 // as COMPACTING PASSES like the hex8 locate: a pass performs at most one inverse transform per
 // still-open target (candidate j of its list) and re-queues the unresolved ones densely as (target,
@@ -367,7 +445,7 @@ constexpr int kGllWaveQueue = 256;
 constexpr int kGllLazyK = 8;   // candidates asked of the kNN stage up front by mm_interpolate_gll
 constexpr int kGllWalkFrom = 3; // passes that advance one candidate before the lanes walk their lists
 
-template <int ORDER, int DIM, typename IDX>
+template <int ORDER, int DIM, typename IDX, bool DEFER = false>
 __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
                                                              const IDX *__restrict__ nn,
                                                              const double *__restrict__ gll_points, i64 nelem,
@@ -453,7 +531,7 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k
                     for (int d = 0; d < DIM; ++d)
                         if (!(fabs(xi[d]) < tolerance)) inside = false;
                     if (inside) {
-                        gll_emit<ORDER, DIM>(em, i, e, xi, true, nelem);
+                        gll_emit<ORDER, DIM, DEFER>(em, i, e, xi, true, nelem);
                         found = true;
                     }
                 }
@@ -476,9 +554,9 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k
                         if (v > 1.02) v = 1.02;
                         best_xi[d] = v;
                     }
-                    gll_emit<ORDER, DIM>(em, i, best_elem, best_xi, true, nelem);
+                    gll_emit<ORDER, DIM, DEFER>(em, i, best_elem, best_xi, true, nelem);
                 } else {
-                    gll_emit<ORDER, DIM>(em, i, 0, best_xi, false, nelem);
+                    gll_emit<ORDER, DIM, DEFER>(em, i, 0, best_xi, false, nelem);
                     missing = true;
                 }
             }
@@ -504,7 +582,7 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k
 // lanes of an element the same address (broadcast) -- instead of going back to L1/L2 for 3 KB per step.  A
 // wave with more distinct elements (thinly populated elements) takes further turns of the stage/solve
 // loop.  Same arithmetic, same results as locate_gll_pass_kernel with q_in == null.
-template <int ORDER, int DIM, typename IDX>
+template <int ORDER, int DIM, typename IDX, bool DEFER = false>
 __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_first_pass_kernel(
     i64 k, int kavail, i64 npoints, const IDX *__restrict__ nn, const double *__restrict__ gll_points, i64 nelem,
     const double *__restrict__ points, double tolerance, int snap_to_nearest, GllEmit em,
@@ -597,7 +675,7 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_first_pass_kernel
                     for (int d = 0; d < DIM; ++d)
                         if (!(fabs(xi[d]) < tolerance)) inside = false;
                     if (inside) {
-                        gll_emit<ORDER, DIM>(em, i, e, xi, true, nelem);
+                        gll_emit<ORDER, DIM, DEFER>(em, i, e, xi, true, nelem);
                         found = true;
                     }
                 }
@@ -625,9 +703,9 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_first_pass_kernel
                     if (v > 1.02) v = 1.02;
                     best_xi[d] = v;
                 }
-                gll_emit<ORDER, DIM>(em, i, best_elem, best_xi, true, nelem);
+                gll_emit<ORDER, DIM, DEFER>(em, i, best_elem, best_xi, true, nelem);
             } else {
-                gll_emit<ORDER, DIM>(em, i, 0, best_xi, false, nelem);
+                gll_emit<ORDER, DIM, DEFER>(em, i, 0, best_xi, false, nelem);
                 missing = true;
             }
         }
@@ -719,7 +797,7 @@ __global__ __launch_bounds__(256) void gll_queue_ids_kernel(const int2 *__restri
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) list[t] = q[t].x;
 }
 
-template <int ORDER, int DIM, typename IDX>
+template <int ORDER, int DIM, typename IDX, bool DEFER = false>
 int launch_locate(mm_context *ctx, i64 k, int kavail, i64 npoints, const IDX *nn, const double *gll, i64 nelem,
                   const double *pts, double tol, int snap, const GllEmit &em, unsigned long long *nmiss,
                   const int *order, int2 *qa, int2 *qb, int *counters, double *best_state, i64 *best_elem_state,
@@ -752,16 +830,16 @@ int launch_locate(mm_context *ctx, i64 k, int kavail, i64 npoints, const IDX *nn
         const i64 avail = full ? k : (i64)kavail;
         const int walk = c >= walk_from ? 1 : 0;
         if (c == 0 && k > 0 && nelem > 0) {
-            hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0,
+            hipLaunchKernelGGL((locate_gll_first_pass_kernel<ORDER, DIM, IDX, DEFER>), dim3((unsigned)grid), dim3(64), 0,
                                ctx->stream, k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, order, q_out,
                                counters + c + 1, best_state, best_elem_state);
         } else if (full) {
-            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, int>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, int, DEFER>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
                                k, (int)k, npoints, (const int *)lazy->nn_full, gll, nelem, pts, tol, snap, em, nmiss,
                                (const int *)nullptr, q_in, counters + c, q_out, counters + c + 1, best_state,
                                best_elem_state, walk);
         } else {
-            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, IDX>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL((locate_gll_pass_kernel<ORDER, DIM, IDX, DEFER>), dim3((unsigned)grid), dim3(64), 0, ctx->stream,
                                k, kavail, npoints, nn, gll, nelem, pts, tol, snap, em, nmiss, c == 0 ? order : nullptr,
                                q_in, c == 0 ? nullptr : counters + c, q_out, counters + c + 1, best_state,
                                best_elem_state, walk);
@@ -979,11 +1057,20 @@ static int locate_gll_run(mm_context *ctx, int order, int dim, i64 k, int kavail
         visit = ord;
     }
     rc = MM_OK;
+    // (deferred values: only the fused pipeline's int32 lists ask for them)
+    constexpr bool kCanDefer = sizeof(IDX) == sizeof(int);
+    const bool defer = kCanDefer && em.xi_defer != nullptr;
 #define MM_GLL_CASE(O, D)                                                                                          \
-    if (order == O && dim == D)                                                                                    \
-        rc = launch_locate<O, D, IDX>(ctx, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,       \
-                                      snap_to_nearest, em, nm, visit, qa, qb, counters, best_state, best_elem_state, \
-                                      lazy, id_list);
+    if (order == O && dim == D) {                                                                                  \
+        if (defer)                                                                                                 \
+            rc = launch_locate<O, D, IDX, kCanDefer>(ctx, k, kavail, npoints, nn, gll_points_d, nelem, points_d,   \
+                                                     tolerance, snap_to_nearest, em, nm, visit, qa, qb, counters,  \
+                                                     best_state, best_elem_state, lazy, id_list);                  \
+        else                                                                                                       \
+            rc = launch_locate<O, D, IDX>(ctx, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,   \
+                                          snap_to_nearest, em, nm, visit, qa, qb, counters, best_state,            \
+                                          best_elem_state, lazy, id_list);                                         \
+    }
     MM_GLL_CASE(1, 2) MM_GLL_CASE(1, 3) MM_GLL_CASE(2, 2) MM_GLL_CASE(2, 3) MM_GLL_CASE(4, 2) MM_GLL_CASE(4, 3)
 #undef MM_GLL_CASE
     if (rc != MM_OK) return rc;
@@ -1103,10 +1190,33 @@ extern "C" int64_t mm_interpolate_gll(mm_context *ctx, int order, int dim, const
         mm_stage_begin(ctx, MM_STAGE_LOCATE);
         GllEmit em = {(i64 *)elem_out_d, coeffs_out_d, ncomp > 0 ? fields_d : nullptr, ncomp > 0 ? out_d : nullptr,
                       (int)ncomp};
+        // values without the operator: the locate kernels leave {element, xi}, the sums are formed afterwards
+        static const bool defer_on = !(getenv("MM_GLL_DEFER") && atoi(getenv("MM_GLL_DEFER")) == 0);
+        const bool defer = defer_on && em.out && !em.coeffs;
+        if (defer) {
+            rc = mm_buffer_get(ctx, MM_BUF_W, (size_t)npoints * dim * sizeof(double), (void **)&em.xi_defer);
+            if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_ENC, (size_t)npoints * sizeof(int), (void **)&em.elem_defer);
+        }
         GllLazy lz = {ix, nn_full};
-        rc = locate_gll_run<int>(ctx, order, dim, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,
-                                 snap_to_nearest, em, lazy_on ? &lz : nullptr);
+        if (rc == MM_OK)
+            rc = locate_gll_run<int>(ctx, order, dim, k, kavail, npoints, nn, gll_points_d, nelem, points_d, tolerance,
+                                     snap_to_nearest, em, lazy_on ? &lz : nullptr);
         mm_stage_end(ctx, MM_STAGE_LOCATE);
+        if (rc == MM_OK && defer) {
+            mm_stage_begin(ctx, MM_STAGE_GATHER);
+            const dim3 g((unsigned)((npoints + 255) / 256)), b(256);
+#define MM_GLL_VALUES(O, D)                                                                                           \
+    if (order == O && dim == D)                                                                                       \
+        hipLaunchKernelGGL((gll_values_kernel<O, D>), g, b, 0, ctx->stream, (i64)npoints, (const int *)em.elem_defer,  \
+                           (const double *)em.xi_defer, fields_d, (i64)nelem, (int)ncomp, out_d);
+            MM_GLL_VALUES(1, 2) MM_GLL_VALUES(1, 3) MM_GLL_VALUES(2, 2) MM_GLL_VALUES(2, 3) MM_GLL_VALUES(4, 2) MM_GLL_VALUES(4, 3)
+#undef MM_GLL_VALUES
+            mm_stage_end(ctx, MM_STAGE_GATHER);
+            if (hipGetLastError() != hipSuccess) {
+                mm_set_error(MM_ERR_HIP, "gll_values_kernel launch failed");
+                rc = MM_ERR_HIP;
+            }
+        }
     }
     int64_t result = rc;
     if (rc == MM_OK) {

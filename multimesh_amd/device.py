@@ -466,17 +466,20 @@ class Context:
                          "mm_fluid_solid_fix"))
 
     # ---- A11 ----------------------------------------------------------------------------
-    def unique_points(self, points, unique_out=None, inverse_out=None):
+    def unique_points(self, points, unique_out=None, inverse_out=None, ordered=True):
         """``np.unique(points, axis=0, return_inverse=True)`` (reference utils.py:484-488) on the
         device: (unique f64[U, dim] in lexicographic order, inverse int64[N]).  ``unique_out`` f64[N, dim] /
-        ``inverse_out`` int64[N]: caller-owned device buffers to write into (no allocation in the call)."""
+        ``inverse_out`` int64[N]: caller-owned device buffers to write into (no allocation in the call).
+        ``ordered=False``: the unique rows in the order of their first occurrence instead (a hash table, 2-3x
+        faster) -- enough wherever the rows are only interpolated and scattered back through the inverse."""
         pts = self.asdevice(points, np.float64)
         n, dim = pts.shape
         uniq = self.empty((max(n, 1), dim), np.float64) if unique_out is None else self.asdevice(unique_out, np.float64)
         inv = self.empty((max(n, 1),), np.int64) if inverse_out is None else self.asdevice(inverse_out, np.int64)
         if uniq.size < n * dim or inv.size < n:
             raise ValueError("unique_out / inverse_out too small: need [N, dim] and [N]")
-        nu = check(self.lib.mm_unique_points(self.handle, pts.ptr, n, dim, uniq.ptr, inv.ptr), "mm_unique_points")
+        fn = self.lib.mm_unique_points if ordered else self.lib.mm_unique_points_any_order
+        nu = check(fn(self.handle, pts.ptr, n, dim, uniq.ptr, inv.ptr), "mm_unique_points")
         return (DeviceArray(self, uniq.ptr, (int(nu), dim), np.float64, owner=False, keepalive=uniq),
                 DeviceArray(self, inv.ptr, (n,), np.int64, owner=False, keepalive=inv))
 

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "mm_locate_hex8", "mm_gather", "mm_interpolate_hex8", "mm_interpolate_hex8_host", "mm_locate_gll", "mm_gather_elem",
     "mm_scatter_elements", "mm_fluid_solid_fix", "mm_set_profiling", "mm_last_timings", "mm_set_lazy_lists", "mm_unique_points", "mm_locate_gll_bbox", "mm_interpolate_gll",
     "mm_set_fp_mode", "mm_get_fp_mode", "mm_last_locate_stats",
-    "mm_source_create", "mm_source_destroy", "mm_interpolate_hex8_on",
+    "mm_source_create", "mm_source_destroy", "mm_interpolate_hex8_on", "mm_points_to_elements", "mm_unique_points_any_order",
 )
 
 
@@ -137,6 +137,10 @@ def load_lib():
     lib.mm_unique_points.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp]
     lib.mm_set_lazy_lists.restype = C.c_int
     lib.mm_set_lazy_lists.argtypes = [vp, C.c_int]
+    lib.mm_unique_points_any_order.restype = C.c_int64
+    lib.mm_unique_points_any_order.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp]
+    lib.mm_points_to_elements.restype = C.c_int
+    lib.mm_points_to_elements.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.mm_source_create.restype = C.c_int
     lib.mm_source_create.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp)]
     lib.mm_source_destroy.restype = None

@@ -200,6 +200,58 @@ def test_unique_points_runs_of_equal_x(kind):
     ctx.close()
 
 
+def _first_occurrence_form(pts):
+    """What mm_unique_points_any_order must return: np.unique's classes in the order of their first row."""
+    n = len(pts)
+    ru, rinv = np.unique(pts, axis=0, return_inverse=True)
+    rinv = rinv.reshape(-1)
+    first = np.full(len(ru), n, dtype=np.int64)
+    np.minimum.at(first, rinv, np.arange(n))
+    order = np.argsort(first)
+    pos = np.empty(len(ru), dtype=np.int64)
+    pos[order] = np.arange(len(ru))
+    return pts[first[order]] + 0.0, pos[rinv]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gll3", "gll2", "lattice", "few_values", "signed_zeros", "one_row", "all_equal"])
+def test_unique_points_any_order_is_the_same_collapse_without_the_sort(kind):
+    # the order-free form (a hash table: reference interpolator.py:823 / :1079-1081 only ever scatter values back through the
+    # inverse): the SAME classes as np.unique, rows in the order of their first occurrence, an inverse that rebuilds the input;
+    # deterministic (two runs agree) whatever the order of the atomics
+    from multimesh_amd.device import Context
+    from multimesh_amd import synth
+    rng = np.random.default_rng(11)
+    if kind == "gll3":
+        pts = synth.gll_mesh(12, 4, seed=3, dim=3).reshape(-1, 3)
+    elif kind == "gll2":
+        pts = synth.gll_mesh(60, 4, seed=4, dim=2).reshape(-1, 2)
+    elif kind == "lattice":
+        g = np.arange(40, dtype=np.float64) / 39
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+        pts = np.concatenate([pts, pts[rng.integers(0, len(pts), size=50_000)]])[rng.permutation(len(pts) + 50_000)]
+    elif kind == "few_values":
+        pts = rng.integers(-3, 4, size=(300_000, 3)).astype(np.float64)      # 343 classes: long chains on few slots
+    elif kind == "signed_zeros":
+        pts = rng.integers(-1, 2, size=(5000, 2)).astype(np.float64) * rng.choice([1.0, -0.0], size=(5000, 2))
+    elif kind == "one_row":
+        pts = np.array([[1.0, 2.0, 3.0]])
+    else:
+        pts = np.tile(np.array([[0.25, -7.0, 1e300]]), (10_000, 1))
+    pts = np.ascontiguousarray(pts)
+    ctx = Context(0)
+    try:
+        u, inv = ctx.unique_points(pts, ordered=False)
+        u, inv = u.numpy(), inv.numpy()
+        want_u, want_inv = _first_occurrence_form(pts)
+        assert u.shape == want_u.shape and np.array_equal(u, want_u) and np.array_equal(inv, want_inv)
+        assert np.array_equal(u[inv], pts) and not np.signbit(u[u == 0]).any()
+        u2, inv2 = ctx.unique_points(pts, ordered=False)
+        assert np.array_equal(u2.numpy(), u) and np.array_equal(inv2.numpy(), inv)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_unique_points_edge_cases():
     from multimesh_amd.device import Context

@@ -1,4 +1,6 @@
-"""Randomised check of mm_unique_points against np.unique(axis=0, return_inverse=True)."""
+"""Randomised check of mm_unique_points against np.unique(axis=0, return_inverse=True), and of the order-free form
+mm_unique_points_any_order: the same SET of unique rows, in the order of their first occurrence, and an inverse that
+rebuilds the input."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -32,6 +34,18 @@ for case in range(ncases):
     u, inv = u.numpy(), inv.numpy()
     ru, rinv = np.unique(pts, axis=0, return_inverse=True)
     good = u.shape == ru.shape and np.array_equal(u, ru) and np.array_equal(inv, rinv.reshape(-1)) and np.array_equal(u[inv], pts)
+    # the order-free form: first occurrences, ascending
+    u2, inv2 = ctx.unique_points(pts, ordered=False)
+    u2, inv2 = u2.numpy(), inv2.numpy()
+    first = np.full(len(ru), n, dtype=np.int64)
+    np.minimum.at(first, rinv.reshape(-1), np.arange(n))
+    order = np.argsort(first)                       # np.unique's classes by first occurrence
+    want_u2 = pts[first[order]] + 0.0               # (-0.0 is stored as +0.0)
+    pos = np.empty(len(ru), dtype=np.int64)
+    pos[order] = np.arange(len(ru))
+    good2 = (u2.shape == ru.shape and np.array_equal(u2, want_u2) and not np.signbit(u2[u2 == 0]).any()
+             and np.array_equal(inv2, pos[rinv.reshape(-1)]) and np.array_equal(u2[inv2], pts))
+    good = good and good2
     print(f"case {case:3d} dim={dim} n={n:7d} {kind:10s} unique={len(ru):7d} -> {'ok' if good else 'MISMATCH'}", flush=True)
     if not good:
         sys.exit(1)
