@@ -1118,7 +1118,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
             line["allgather"] = allgather
             if allgather.get("gathered_equals_single_rank") is False:
                 rc = 1
-        if world == 1 and not args.no_cpu_baseline and not as_rank:
+        if world == 1 and not args.no_cpu_baseline:
             # the oracle's restatement of the same loop on a bounded sample ("port": salvus.fem is absent)
             from oracle import oracle as O
             from scipy.spatial import cKDTree

@@ -443,7 +443,8 @@ __global__ __launch_bounds__(256, MM_GLL_VALUES_WAVES) void gll_values_kernel(i6
 // arrays.  Re-queue entries are batched per wave in LDS (one global atomic per ~200 entries).
 constexpr int kGllWaveQueue = 256;
 constexpr int kGllLazyK = 8;   // candidates asked of the kNN stage up front by mm_interpolate_gll
-constexpr int kGllWalkFrom = 3; // passes that advance one candidate before the lanes walk their lists
+constexpr int kGllWalkFrom = 1; // passes that advance one candidate before the lanes walk their lists (round 4: 1 -- with the
+                                // values formed in a kernel of their own the one-candidate passes 1 and 2 cost more than they save: 3.12 -> 2.92 ms)
 
 template <int ORDER, int DIM, typename IDX, bool DEFER = false>
 __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_pass_kernel(i64 k, int kavail, i64 npoints,
@@ -590,6 +591,9 @@ __global__ __launch_bounds__(64, MM_GLL_WAVES) void locate_gll_first_pass_kernel
     int2 *__restrict__ q_out, int *__restrict__ q_out_count, double *__restrict__ best_state,
     i64 *__restrict__ best_elem_state)
 {
+    // (Round 4 also sent the LATER passes through this kernel, {target, next candidate} queue entries in the visiting
+    // order: slower -- a wave of open targets spans many more than two elements and takes a turn of the stage / solve
+    // loop for every pair: 0.9 ms a pass at cfg5's shape against 0.4 for the per-lane kernel.  Taken out again.)
     using G = Gll<ORDER, DIM>;
     constexpr int P = G::P;
     constexpr int kNodeDoubles = P * DIM;
