@@ -296,10 +296,14 @@ def cpu_baseline(pa, ca, pb, fields, k, sample_stride):
         "unit": "points/s",
         "cores": 1,
         "kind": "reference" if use_ref else "port",
-        "sample": (f"EXTRAPOLATED from a 1/{sample_stride} sample: full {len(cen)}-element source (centroid {t_cen:.2f}s + "
-                   f"cKDTree build {t_build:.2f}s) + every {sample_stride}th target ({len(sample)} points: query "
-                   f"{t_query:.2f}s, locate {t_locate:.2f}s, gather {t_gather:.3f}s), per-point cost extrapolated to "
-                   f"{len(pb)} targets; host has {os.cpu_count()} cores, path is single-threaded like the reference"),
+        "sample": ((f"MEASURED on all {len(pb)} targets (no extrapolation): full {len(cen)}-element source (centroid {t_cen:.2f}s + "
+                    f"cKDTree build {t_build:.2f}s), query {t_query:.2f}s, locate {t_locate:.2f}s, gather {t_gather:.3f}s; host has "
+                    f"{os.cpu_count()} cores, path is single-threaded like the reference") if sample_stride == 1 else
+                   (f"EXTRAPOLATED from a 1/{sample_stride} sample: full {len(cen)}-element source (centroid {t_cen:.2f}s + "
+                    f"cKDTree build {t_build:.2f}s) + every {sample_stride}th target ({len(sample)} points: query "
+                    f"{t_query:.2f}s, locate {t_locate:.2f}s, gather {t_gather:.3f}s), per-point cost extrapolated to "
+                    f"{len(pb)} targets; host has {os.cpu_count()} cores, path is single-threaded like the reference; "
+                    "profiles/r04_cpu_full.json holds one run over ALL targets: 283.8 k points/s")),
         "nfailed": int(nf),
         "all_cores": all_cores,
     }, (sample_stride, enc, w, vals)
@@ -614,6 +618,7 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(dev_index, stream=stream)
     ctx.set_fp_mode(args.fp_mode)
+    COUNTER_KEY["locate_pass0"] = "locate_pass_kernel" if args.fp_mode == counter_profile_mode() or counter_profile_mode() is None else "locate_pass_kernel_exact"
     KERNEL_OF_STAGE["locate_pass0"] = LOCATE_KERNEL[args.fp_mode]
     BOUND_OF_STAGE["locate_pass0"] = LOCATE_BOUND[args.fp_mode]
     # Stage timers cost the stream two events per stage (~5 us each between kernels, ~40 us per step for all seven):
@@ -829,8 +834,11 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
         roofline_valu = None
         counters_mode = counter_profile_mode()
         if args.workload == "metric" and world == 1 and not as_rank and n_local == 10_077_696:
+            # (profiles since round 4 hold both instances of the locate pass: "locate_pass_kernel" = the profile's own
+            # mode, "locate_pass_kernel_exact" the reference arithmetic beside it)
+            have_locate = counters_mode == args.fp_mode or (counters_mode == "tol" and args.fp_mode == "exact")
             roofline_valu = {s: valu_floor(s, stages[s]["ms"]) for s in ("knn_cell", "locate_pass0")
-                             if stages[s].get("ms") and (s != "locate_pass0" or counters_mode == args.fp_mode)}
+                             if stages[s].get("ms") and (s != "locate_pass0" or have_locate)}
             for v in roofline_valu.values():
                 if v and v.get("frac") and v["frac"] > 1.0:     # a floor above the measured time is not a floor
                     v["note"] = "counter profile does not match this build: " + v.get("note", "")
@@ -869,7 +877,8 @@ def run_rank_hex8(args, out, torch, dist, rank, world, dev_index, dev, D):
             "roofline_valu": roofline_valu if roofline_valu is not None else {
                 "omitted": "instruction-count floors are only printed for the launch the committed counter passes were taken on "
                            "(--workload metric, one rank)"},
-            "roofline_memory_side": memory_side_profile(dominant, stages[dominant]["ms"]) if args.workload == "metric" else None,
+            "roofline_memory_side": ({st: memory_side_profile(st, stages[st]["ms"]) for st in ("knn_cell", "locate_pass0")}
+                                     if args.workload == "metric" and args.fp_mode == "tol" else None),
             "roofline_end_to_end": {"algorithmic_bytes_per_target": e2e_bytes,
                                     "achieved_GBps_per_gpu": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(e2e_bytes * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -1076,7 +1085,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
         act = n_src_elem * P * (dim * 8 + 8 * ncomp) + n_local * (dim * 8 + 4 * min(k, 8) + 8 * ncomp)
         frac_alg = alg / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         roofline = {"bound": "hbm", "limited_by": "valu (fp64 Newton on the 125-node map)",
-                    "kernel": "locate_gll_first_pass_kernel<4, 3, int> + locate_gll_pass_kernel<4, 3, int> (all passes of the stage)",
+                    "kernel": "locate_gll_first_pass_kernel<4, 3, int, true> + locate_gll_pass_kernel<4, 3, int, true> (all passes of the stage)",
                     "stage": "locate",
                     "achieved": round(alg / (loc_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     # (a section-8(d) figure above the peak is not a fraction of anything: the 3000 + 1000 B of control
@@ -1108,7 +1117,7 @@ def run_rank_gll(args, out, torch, dist, rank, world, dev_index, dev, D):
             # default cfg5 sizes with tools/knn_counters.sh; per launch, rescaled by this rank's share of the targets)
             "roofline_valu": {"locate": valu_floor("locate", loc_ms, scale=n_local / max(n_unique, 1), pattern="*_gll_counters.json",
                                                    key=["locate_gll_first_pass_kernel", "locate_gll_pass_kernel"], run_steps=3,
-                                                   kernel="locate_gll_first_pass_kernel<4, 3, int> + locate_gll_pass_kernel<4, 3, int>")},
+                                                   kernel="locate_gll_first_pass_kernel<4, 3, int, true> + locate_gll_pass_kernel<4, 3, int, true>")},
             "stages": {"unique_points": {"ms": round(st["unique_ms"] / steps, 4),
                                          "note": "mm_unique_points_any_order (hash table; the unique rows are only interpolated and scattered back) over all element-nodal target points (replicated on every rank)"},
                        **{s: {"ms": round(v, 4)} for s, v in sm.items() if v > 0}},

@@ -108,8 +108,8 @@ __device__ __forceinline__ void gll_pin(double (&v)[N])
 #ifndef MM_GLL_WAVES
 #define MM_GLL_WAVES 1
 #endif
-#ifndef MM_GLL_PIN_SUMS   // 1: the partial sums of the map are pinned at every row of nodes (see gll_pin)
-#define MM_GLL_PIN_SUMS 1
+#ifndef MM_GLL_PIN_SUMS   // 1: the partial sums of the MAP are pinned at every row of nodes as well (see gll_pin).  Measured at
+#define MM_GLL_PIN_SUMS 0 //    cfg5's shape and left off: it serialises the walking passes' node loads (0.46 -> 1.0 ms a pass)
 #endif
 #ifndef MM_GLL_VALUES_WAVES   // waves per SIMD gll_values_kernel is compiled for
 #define MM_GLL_VALUES_WAVES 2
@@ -135,11 +135,12 @@ struct Gll {
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xi[d] = 0.0;
         if (DIM == 3 && ORDER >= 2) {
-            // Start from the solution of the element's eight CORNERS' trilinear map (the hex8 Newton of
-            // mm_newton_hex8.h, at most kGllGuessTrips trips of ~300 fp64 instructions against ~1.2 k for one step
-            // here, the converged trip's update applied as well): a straight-sided element -- its nodes the trilinear images of the GLL points -- is then left
+            // Start from the solution of the element's eight CORNERS' trilinear map (newton_hex8_start of
+            // mm_newton_hex8.h: at most kGllGuessTrips trips of ~80 fp64 instructions -- the polynomial form of the map,
+            // round 4; rounds 2-3 ran the reference-order hex8 iteration here, ~300 a trip -- against ~1.2 k for one step
+            // here): a straight-sided element -- its nodes the trilinear images of the GLL points -- is then left
             // after one or two steps instead of five, a curved one after three.  Same arithmetic as the oracle's start
-            // (mmo_gll_inverse_transform; the hex8 solve is bit-identical in both: tests/test_newton_host.py).  A start
+            // (mmo_gll_inverse_transform -> mmo_hex8_start; bit-identical: tests/test_newton_host.py).  A start
             // that is not finite or far outside is not used.
             double cx[8], cy[8], cz[8];
 #pragma unroll
@@ -150,7 +151,11 @@ struct Gll {
                 cz[c] = ctrl[3 * node + 2];
             }
             double q[3];
+#ifdef MM_GLL_OLD_START   // timing experiment only (the oracle follows newton_hex8_start)
             (void)newton_hex8<true>(pnt[0], pnt[1], pnt[DIM - 1], cx, cy, cz, q, kGllGuessTrips);
+#else
+            newton_hex8_start(pnt[0], pnt[1], pnt[DIM - 1], cx, cy, cz, q, kGllGuessTrips);
+#endif
             if (fabs(q[0]) <= kGllGuessMax && fabs(q[1]) <= kGllGuessMax && fabs(q[2]) <= kGllGuessMax) {
                 xi[0] = q[0];
                 xi[1] = q[1];

@@ -396,3 +396,52 @@ MM_HD void weights_hex8_fast(const double (&xi)[3], double (&w)[8])
     MM_W(0) MM_W(1) MM_W(2) MM_W(3) MM_W(4) MM_W(5) MM_W(6) MM_W(7)
 #undef MM_W
 }
+
+// The start of a 3-D GLL inverse transform (mm_locate_gll.hip, round 4): Newton on the element's eight CORNERS' trilinear
+// map in the polynomial form above -- at most max_it trips, every trip's update applied, stopped after the trip whose
+// update is below 1e-9 (the 125-node iteration behind it polishes) or when an iterate stops being finite.  The GLL path's
+// arithmetic is this project's own definition (salvus.fem is absent: parity unpinned), so unlike newton_hex8_fast there is
+// nothing to certify: the oracle's mmo_hex8_start restates THESE operations (fma for fma, an exact division where the hex8
+// path refines a reciprocal) and tests/test_newton_host.py compares the two bit for bit.  ~80 fp64 instructions per trip
+// against the reference-order iteration's ~300, a third of its registers.
+MM_HD void newton_hex8_start(const double px, const double py, const double pz, const double (&x)[8], const double (&y)[8],
+                             const double (&z)[8], double (&xi)[3], const int max_it)
+{
+    double cx[8], cy[8], cz[8];
+    hex8_poly_axis(x, cx);
+    hex8_poly_axis(y, cy);
+    hex8_poly_axis(z, cz);
+    const double q0[3] = {__builtin_fma(8.0, px, -cx[0]), __builtin_fma(8.0, py, -cy[0]), __builtin_fma(8.0, pz, -cz[0])};
+    double ar[3] = {cx[1], cy[1], cz[1]}, as[3] = {cx[2], cy[2], cz[2]}, at[3] = {cx[3], cy[3], cz[3]};
+    double res[3] = {q0[0], q0[1], q0[2]};
+    double r = 0., s = 0., t = 0.;
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int it = 0; it < max_it; ++it) {
+        double nr[3], ns[3], nt[3];
+#define MM_CROSS(o, a, b)                                      \
+    o[0] = __builtin_fma(a[1], b[2], -(a[2] * b[1]));          \
+    o[1] = __builtin_fma(a[2], b[0], -(a[0] * b[2]));          \
+    o[2] = __builtin_fma(a[0], b[1], -(a[1] * b[0]));
+        MM_CROSS(nr, as, at)
+        MM_CROSS(ns, at, ar)
+        MM_CROSS(nt, ar, as)
+#undef MM_CROSS
+        const double det = __builtin_fma(ar[2], nr[2], __builtin_fma(ar[1], nr[1], ar[0] * nr[0]));
+        const double rdet = 1.0 / det;
+        const double dr = fast_dot(res, nr), ds = fast_dot(res, ns), dt = fast_dot(res, nt);
+        const double m = mm_max3abs(dr, ds, dt) * __builtin_fabs(rdet);
+        r = __builtin_fma(dr, rdet, r);
+        s = __builtin_fma(ds, rdet, s);
+        t = __builtin_fma(dt, rdet, t);
+        if (!(m >= 1e-9)) break;               // converged (or not a number: the caller looks at the iterate)
+        if (!(mm_max3abs(r, s, t) <= 1e3)) break;   // running away: not a usable start
+        fast_axis(cx, q0[0], r, s, t, ar[0], as[0], at[0], res[0]);
+        fast_axis(cy, q0[1], r, s, t, ar[1], as[1], at[1], res[1]);
+        fast_axis(cz, q0[2], r, s, t, ar[2], as[2], at[2], res[2]);
+    }
+    xi[0] = r;
+    xi[1] = s;
+    xi[2] = t;
+}

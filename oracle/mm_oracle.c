@@ -129,6 +129,86 @@ int mmo_hex8_newton_start(const double pnt[3], const double vtx[8][3], double xi
     return hex8_newton_capped(pnt, vtx, xi, NULL, cap, 1);
 }
 
+/* The start of a 3-D GLL inverse transform since round 4 (the GLL section's own arithmetic: salvus.fem is absent, parity
+ * unpinned): Newton on the eight corners' trilinear map written as the polynomial c0 + r cR + s cS + t cT + rs cRS + rt cRT +
+ * st cST + rst cRST (coefficients at 8x: a Walsh-Hadamard butterfly of the corners), Cramer's rule by cross products,
+ * every partial result by the fused multiply-adds spelled out here -- operation for operation what newton_hex8_start of
+ * multimesh_amd/csrc/mm_newton_hex8.h does (tests/test_newton_host.py compares the two bit for bit).  At most cap trips,
+ * every update applied; stops after an update below 1e-9 or when an iterate leaves [-1e3, 1e3] / is not a number. */
+static void hex8_poly_axis(const double v[8], double c[8])
+{
+    const double s_mm = v[0] + v[3], d_mm = v[3] - v[0];
+    const double s_pm = v[1] + v[2], d_pm = v[2] - v[1];
+    const double s_mp = v[4] + v[5], d_mp = v[5] - v[4];
+    const double s_pp = v[7] + v[6], d_pp = v[6] - v[7];
+    const double ss_m = s_mm + s_pm, sd_m = s_pm - s_mm;
+    const double ss_p = s_mp + s_pp, sd_p = s_pp - s_mp;
+    const double ds_m = d_mm + d_pm, dd_m = d_pm - d_mm;
+    const double ds_p = d_mp + d_pp, dd_p = d_pp - d_mp;
+    c[0] = ss_m + ss_p;
+    c[3] = ss_p - ss_m;
+    c[2] = sd_m + sd_p;
+    c[6] = sd_p - sd_m;
+    c[1] = ds_m + ds_p;
+    c[5] = ds_p - ds_m;
+    c[4] = dd_m + dd_p;
+    c[7] = dd_p - dd_m;
+}
+
+static void hex8_fast_axis(const double c[8], double q0, double r, double s, double t, double *gr, double *gs, double *gt,
+                           double *res)
+{
+    const double A = fma(t, c[7], c[4]);
+    const double D = fma(t, c[6], c[2]);
+    *gr = fma(s, A, fma(t, c[5], c[1]));
+    *gs = fma(r, A, D);
+    *gt = fma(s, fma(r, c[7], c[6]), fma(r, c[5], c[3]));
+    *res = fma(-t, c[3], fma(-s, D, fma(-r, *gr, q0)));
+}
+
+static void hex8_cross(double o[3], const double a[3], const double b[3])
+{
+    o[0] = fma(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fma(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+
+static double hex8_dot(const double a[3], const double b[3]) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+
+static double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
+
+void mmo_hex8_start(const double pnt[3], const double vtx[8][3], double xi[3], int cap)
+{
+    double col[8], c[3][8];
+    for (int a = 0; a < 3; ++a) {
+        for (int n = 0; n < 8; ++n) col[n] = vtx[n][a];
+        hex8_poly_axis(col, c[a]);
+    }
+    const double q0[3] = {fma(8.0, pnt[0], -c[0][0]), fma(8.0, pnt[1], -c[1][0]), fma(8.0, pnt[2], -c[2][0])};
+    double ar[3] = {c[0][1], c[1][1], c[2][1]}, as[3] = {c[0][2], c[1][2], c[2][2]}, at[3] = {c[0][3], c[1][3], c[2][3]};
+    double res[3] = {q0[0], q0[1], q0[2]};
+    double r = 0., s = 0., t = 0.;
+    for (int it = 0; it < cap; ++it) {
+        double nr[3], ns[3], nt[3];
+        hex8_cross(nr, as, at);
+        hex8_cross(ns, at, ar);
+        hex8_cross(nt, ar, as);
+        const double det = fma(ar[2], nr[2], fma(ar[1], nr[1], ar[0] * nr[0]));
+        const double rdet = 1.0 / det;
+        const double dr = hex8_dot(res, nr), ds = hex8_dot(res, ns), dt = hex8_dot(res, nt);
+        const double m = max3abs(dr, ds, dt) * fabs(rdet);
+        r = fma(dr, rdet, r);
+        s = fma(ds, rdet, s);
+        t = fma(dt, rdet, t);
+        if (!(m >= 1e-9)) break;
+        if (!(max3abs(r, s, t) <= 1e3)) break;
+        for (int a = 0; a < 3; ++a) hex8_fast_axis(c[a], q0[a], r, s, t, &ar[a], &as[a], &at[a], &res[a]);
+    }
+    xi[0] = r;
+    xi[1] = s;
+    xi[2] = t;
+}
+
 /* cap: the reference's 50 (:264); the GLL section starts its own iteration from a few trips of this one, with
  * polish != 0: the trip that finds the residual converged still applies its update before it returns. */
 static int hex8_newton_capped(const double pnt[3], const double vtx[8][3], double xi[3], int *iters, int cap, int polish)
@@ -549,8 +629,8 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
     gll_nodes(order, g);
     for (int d = 0; d < dim; ++d) xi[d] = 0.0;
     if (dim == 3 && order >= 2) {
-        /* Start from the solution of the eight CORNERS' trilinear map: at most 8 trips of the hex8 iteration above,
-         * the converged trip's update applied as well (corner c of trilinearinterpolator.c:8-10 is the control node at the matching end of every axis).  A start
+        /* Start from the solution of the eight CORNERS' trilinear map: at most 8 trips of mmo_hex8_start above (rounds 2-3:
+         * of the reference-order hex8 iteration, the converged trip's update applied as well) (corner c of trilinearinterpolator.c:8-10 is the control node at the matching end of every axis).  A start
          * that is not finite or lies beyond 3 is not used.  Part of this path's definition, like the fma order
          * below: the HIP kernel does the same. */
         double vtx[8][3], q[3];
@@ -558,7 +638,7 @@ void mmo_gll_inverse_transform(int order, int dim, const double *pnt, const doub
             const int node = (kR[c] > 0 ? n - 1 : 0) + n * ((kS[c] > 0 ? n - 1 : 0) + n * (kT[c] > 0 ? n - 1 : 0));
             for (int a = 0; a < 3; ++a) vtx[c][a] = ctrl[3 * node + a];
         }
-        (void)hex8_newton_capped(pnt, (const double(*)[3])vtx, q, NULL, 8, 1);
+        mmo_hex8_start(pnt, (const double(*)[3])vtx, q, 8);
         if (fabs(q[0]) <= 3.0 && fabs(q[1]) <= 3.0 && fabs(q[2]) <= 3.0)
             for (int d = 0; d < 3; ++d) xi[d] = q[d];
     }

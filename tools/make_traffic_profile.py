@@ -10,8 +10,8 @@ kernels whose reads are not 16-byte-per-lane streams; raw_bytes_per_launch = (FE
 import csv, glob, json, sys, collections
 
 KERNELS = {"knn_cell": "knn_lane_kernel", "knn_strip_kernel": "knn_strip_kernel", "centroid": "centroid_",
-           "locate_pass0": "locate_pass_kernel", "gather": "gather8_kernel", "cell_scatter": "cell_scatter_kernel",
-           "target_scatter": "target_scatter_kernel"}
+           "locate_pass0": "locate_pass_kernel<true, int, true, int, true>", "locate_pass0_exact": "locate_pass_kernel<true, int, true, int, false>",
+           "gather": "gather8_kernel", "cell_scatter": "cell_scatter_kernel", "target_scatter": "target_scatter_kernel"}
 
 
 def per_dispatch(d, counter):
