@@ -171,3 +171,40 @@ print("ok")
     env = dict(os.environ, MM_FP_MODE="tol")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_metric_size_10M_tol_against_exact_on_every_target(ctx):
+    # BASELINE's metric configuration (10,077,696 -> 10,077,696, what bench.py runs in MM_FP_TOL): the fused values-only
+    # call and the operator call in both modes on the same GPU -- node ids identical on EVERY target, weights / values within
+    # the tolerance, partition of unity, the trilinear field reproduced; then the oracle (cKDTree over all source centroids
+    # + the C restatement) on a random sample.  Size-independent properties carry the full size, the oracle a sample.
+    from multimesh_amd.device import Context
+
+    pa, ca = synth.hex_mesh(216, seed=1)
+    pb, _ = synth.hex_mesh(216, seed=7)
+    fields = synth.vector_field(pa)[:1]
+    d = [ctx.to_device(x) for x in (pa, ca, pb, fields)]
+    vals, enc, w, nf = ctx.interpolate_hex8(*d, want_operator=True)
+    stats = ctx.last_locate_stats()
+    vals_only, nf_only = ctx.interpolate_hex8(*d)
+    assert nf == nf_only == 0
+    assert np.array_equal(vals_only.numpy(), vals.numpy())            # the two TOL calls agree bit for bit (deterministic)
+    enc_t, w_t, vals_t = enc.numpy(), w.numpy(), vals.numpy()
+    del enc, w, vals, vals_only
+    ex = Context(0)
+    try:
+        de = [ex.to_device(x) for x in (pa, ca, pb, fields)]
+        vals_e, enc_e, w_e, nf_e = ex.interpolate_hex8(*de, want_operator=True)
+        assert nf_e == 0 and ex.last_locate_stats()["redone_exact"] == 0
+        assert np.array_equal(enc_t, enc_e.numpy())                   # every one of the 10 M targets
+        assert close(w_t, w_e.numpy()) and close(vals_t, vals_e.numpy(), 8 * np.abs(fields).max())
+    finally:
+        ex.close()
+    assert 0 < stats["redone_exact"] < 0.05 * len(pb)
+    assert np.abs(w_t.sum(axis=1) - 1).max() < 1e-13
+    assert np.abs(vals_t[:, 0] - synth.field_linear(pb)).max() < 1e-7
+    pick = np.sort(np.random.default_rng(3).choice(len(pb), size=20_000, replace=False))
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb[pick], 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb[pick])
+    assert nf_o == 0 and np.array_equal(enc_t[pick], enc_o) and close(w_t[pick], w_o)
+    assert close(vals_t[pick], O.gather(fields, enc_o, w_o), 8 * np.abs(fields).max())
