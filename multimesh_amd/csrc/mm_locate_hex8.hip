@@ -669,6 +669,7 @@ __global__ __launch_bounds__(kPassBlock, FAST ? MM_FAST_WAVES : MM_PASS_WAVES) v
                     }
 #endif
                 }
+                MM_LCOUNT(4, outside && valid_elem);   // candidates dropped by the box test (their rows and corners were loaded)
                 if (!outside) {
                     have = true;
                     break;
@@ -940,8 +941,8 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         fprintf(stderr, "[mm_locate] %lld targets; reference-order list %d\n", (long long)npoints, h[15]);
 #ifdef MM_LOCATE_COUNT
-        fprintf(stderr, "[mm_locate] rounds %d (slow tiers %d), active lanes %d, solves %d, accepted %d, sent to the next tier %d\n",
-                h[0], h[6], h[1], h[2], h[3], h[5]);
+        fprintf(stderr, "[mm_locate] rounds %d (slow tiers %d), active lanes %d, solves %d, accepted %d, sent to the next tier %d, "
+                        "candidates dropped by the box test %d\n", h[0], h[6], h[1], h[2], h[3], h[5], h[4]);
 #endif
     }
     return MM_OK;

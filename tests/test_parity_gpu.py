@@ -924,3 +924,41 @@ def test_resident_source_gives_the_fused_path_bit_for_bit(ctx, golden):
             assert nfa == nfb == 0 and np.array_equal(a.numpy(), b.numpy())
     finally:
         src.free()
+
+
+# ------------------------------------------------------------------------------- targets that fill part of the grid
+def test_knn_targets_in_a_slab_choose_their_kernel_by_occupied_strips(ctx):
+    # One rank's share of a sharded target set is a slab: the full problem's density inside, nothing outside.  The average
+    # density test (npts >= 2 * ncells) fails for it; the query then counts the lane kernel's work items on the device once
+    # (first call: a readback; later calls of the same sizes: the kept verdict) and takes the lane kernel when the occupied
+    # strips are well filled.  Both calls, dense slab and thin uniform cloud, k = 8 and 20: indices and distances equal
+    # cKDTree's bit for bit.
+    rng = np.random.default_rng(12)
+    src = rng.uniform(size=(400_000, 3))                       # ~50 k cells
+    tree = ctx.knn_build(src)
+    slab = rng.uniform(size=(60_000, 3)) * np.array([0.12, 1.0, 1.0]) + np.array([0.3, 0.0, 0.0])   # 1/8 of the box, 10 per cell
+    thin = rng.uniform(size=(40_000, 3))                       # < 1 per cell everywhere
+    for pts in (slab, thin):
+        for k in (8, 20):
+            want_i, want_d = O.knn_ckdtree(src, pts, k, workers=-1)
+            for _ in range(2):                                  # probe, then the remembered verdict
+                got_i, got_d = tree.query(pts, k, want_dist=True)
+                assert np.array_equal(got_i.numpy(), want_i) and np.array_equal(got_d.numpy(), want_d)
+
+
+def test_a_strong_scaling_shard_equals_its_rows_of_the_whole_run(ctx):
+    # rank 3 of 8 of a strong-scaling run (bench.py --as-rank 3/8): rows shard_bounds(N, 8, 3) of the target mesh, an
+    # x-slab of the domain, through the fused pipeline twice (kernel probe, then the kept verdict) -- bit-equal to the same
+    # rows of the run over the whole target set, in both arithmetics' ids
+    from multimesh_amd.distributed import shard_bounds
+
+    pa, ca = synth.hex_mesh(80, seed=1)
+    pb, _ = synth.hex_mesh(80, seed=7)
+    fields = synth.vector_field(pa)[:2]
+    whole, enc_w, w_w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, want_operator=True)
+    lo, hi = shard_bounds(len(pb), 8, 3)
+    for _ in range(2):
+        part, enc_p, w_p, nfp = ctx.interpolate_hex8(pa, ca, pb[lo:hi], fields, want_operator=True)
+        assert nf == nfp == 0
+        assert np.array_equal(part.numpy(), whole.numpy()[lo:hi])
+        assert np.array_equal(enc_p.numpy(), enc_w.numpy()[lo:hi]) and np.array_equal(w_p.numpy(), w_w.numpy()[lo:hi])
