@@ -1,5 +1,5 @@
 #!/bin/bash
-# (GPU box) one bench run, stage table on one line:  tools/r3_stage_line.sh <tag> [bench args...]
+# (GPU box) one bench run, stage table on one line:  tools/stage_line.sh <tag> [bench args...]
 TAG=$1; shift
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import json,sys
