@@ -77,11 +77,7 @@ __global__ __launch_bounds__(kBlock) void unique_flag_kernel(const int *__restri
                                                              i64 n, int *__restrict__ rep, int *__restrict__ flag)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    if (i == n) {
-        flag[n] = 0;   // (the scan's last entry receives the total)
-        return;
-    }
+    if (i >= n) return;
     const int r = table[slot_of[i]];
     rep[i] = r;
     flag[i] = r == (int)i ? 1 : 0;
@@ -129,11 +125,11 @@ int64_t unique_any_order(mm_context *ctx, const double *pts, i64 n, double *uniq
         return MM_ERR_ALLOC;
     }
     MM_HIP_CHECK(hipMemsetAsync(table, 0xff, (size_t)tsize * sizeof(int), ctx->stream));
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), grid1((unsigned)((n + 1 + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     hipLaunchKernelGGL((unique_insert_kernel<DIM>), grid, block, 0, ctx->stream, pts, n, table, tsize - 1u, slot_of);
-    hipLaunchKernelGGL(unique_flag_kernel, grid1, block, 0, ctx->stream, table, slot_of, n, rep, flag);
+    hipLaunchKernelGGL(unique_flag_kernel, grid, block, 0, ctx->stream, table, slot_of, n, rep, flag);
     MM_HIP_CHECK(hipGetLastError());
-    rc = mm_exclusive_scan_int(ctx, flag, n + 1, rank, tile_sums);
+    rc = mm_exclusive_scan_int(ctx, flag, n, rank, tile_sums);   // rank[0 .. n), rank[n] = the number of unique rows
     if (rc != MM_OK) return rc;
     hipLaunchKernelGGL((unique_emit_kernel<DIM>), grid, block, 0, ctx->stream, pts, n, rep, rank, unique_d, inverse_d);
     MM_HIP_CHECK(hipGetLastError());

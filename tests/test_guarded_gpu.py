@@ -66,6 +66,26 @@ src_g = synth.gll_mesh(4, 4, seed=1, jitter=0.15)
 f = rng.uniform(size=(1, src_g.shape[0], src_g.shape[1]))
 out, missing = ctx.interpolate_gll(4, src_g, ur[::3], f, nelem_to_search=8)
 assert out.numpy().shape[0] == len(ur[::3]) and missing >= 0
+# 5. round 4's entry points: the fused pass in MM_FP_TOL (fast locate instance), a resident source, the order-free
+#    unique, the legacy symbol (sizes found on the device)
+ctx.set_fp_mode("tol")
+vals_t, enc_t, w_t, nf_t = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+ok = w.any(axis=1)
+assert nf_t == nf and np.array_equal(enc_t.numpy()[ok], enc[ok]) and np.abs(w_t.numpy()[ok] - w[ok]).max() <= 1e-12, "MM_FP_TOL"
+ctx.set_fp_mode("exact")
+src_h = ctx.source(pa, ca)
+v_r, nf_r = src_h.interpolate(pb, fields, nelem_to_search=20)
+assert nf_r == nf and np.array_equal(v_r.numpy(), vals.numpy()), "resident source"
+src_h.free()
+u2, inv2 = ctx.unique_points(pts, ordered=False)
+assert len(u2.numpy()) == len(ur) and np.array_equal(u2.numpy()[inv2.numpy()], pts), "unique_points_any_order"
+from multimesh_amd import helpers
+lib = helpers.load_lib()
+nn64 = np.ascontiguousarray(nn, dtype=np.int64)
+enc_l, w_l = np.zeros((len(pb), 8), np.int64), np.zeros((len(pb), 8))
+nf_l = lib.triLinearInterpolator(20, len(pb), nn64, np.ascontiguousarray(synth.reorder_hex8(ca)), enc_l, np.ascontiguousarray(pa), w_l,
+                                 np.ascontiguousarray(pb))
+assert nf_l == nf and np.array_equal(enc_l, enc) and np.array_equal(w_l, w), "legacy symbol"
 print("ok")
 """
 

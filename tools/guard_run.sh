@@ -12,6 +12,8 @@ MM_KNN_KERNEL=lane timeout -k 10 500 python tools/fuzz_knn.py $N 8102 > gpurun_o
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python tools/fuzz_pipeline.py $N 8103 > gpurun_out/guard/fuzz_pipe_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_pipeline rc=$rc"; tail -1 gpurun_out/guard/fuzz_pipe_$TAG.log
 [ $rc -eq 0 ] || exit $rc
+FP_MODE=tol timeout -k 10 500 python tools/fuzz_pipeline.py $N 8106 > gpurun_out/guard/fuzz_pipe_tol_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_pipeline (MM_FP_TOL) rc=$rc"; tail -1 gpurun_out/guard/fuzz_pipe_tol_$TAG.log
+[ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python tools/fuzz_gll.py $N 8104 > gpurun_out/guard/fuzz_gll_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_gll rc=$rc"; tail -1 gpurun_out/guard/fuzz_gll_$TAG.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python tools/fuzz_unique.py $N 8105 > gpurun_out/guard/fuzz_unique_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_unique rc=$rc"; tail -1 gpurun_out/guard/fuzz_unique_$TAG.log
