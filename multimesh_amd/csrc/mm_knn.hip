@@ -314,21 +314,9 @@ struct GuessedBuild {
     int *stat_shift;
 };
 
-static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
-                       bool use_context_buffers, int level, int *level_extra, mm_knn_index **out,
-                       double *sparse_share = nullptr, bool stat_dirty = true, const GuessedBuild *guessed = nullptr)
+// The grid a box and a source count ask for: ~per_cell sources per cell, cubic cells (dims, lo, h, inv_h, ncells of *ix).
+static void grid_layout(const double *box, i64 nsrc, int ndim, double per_cell, mm_knn_index *ix, int *live_axes)
 {
-    static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
-    const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
-    const int slot_xyz = level == 0 ? (int)MM_BUF_SORTED_XYZ : (int)MM_BUF_LEVELS + 2 * (level - 1) + 1;
-    *out = nullptr;
-    mm_knn_index *ix = new (std::nothrow) mm_knn_index();
-    if (!ix) {
-        mm_set_error(MM_ERR_ALLOC, "out of host memory");
-        return MM_ERR_ALLOC;
-    }
-    ix->nsrc = nsrc;
-    ix->ndim = ndim;
     double ext[3] = {0, 0, 0};
     int live = 0;
     double vol = 1.0;
@@ -356,6 +344,50 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
         ncells *= n;
     }
     ix->ncells = ncells;
+    if (live_axes) *live_axes = live;
+}
+
+// The counting sort of a query's targets by the cells of grid gl (count with ranks -> exclusive scan -> scatter of the
+// 32-byte records), on ctx->stream.  counts must be zero.
+static int sort_targets(mm_context *ctx, const GridParams &gl, i64 ncells, int ndim, const double *pts_d, i64 npts,
+                        const int *list, const int *list_count, int *cell_of, int *counts, int *start, int *tile_sums,
+                        double *tsorted)
+{
+    const unsigned gpts = (unsigned)((npts + kBlock - 1) / kBlock);
+    const int ntiles = (int)((ncells + kScanTile - 1) / kScanTile);
+    if (!list && ncells <= kHistCells && npts >= 64 * ncells)   // many targets over few cells (see the kernel)
+        hipLaunchKernelGGL(cell_count_hist_kernel, dim3(256), dim3(kHistBlock), 0, ctx->stream, pts_d, npts, ndim, gl,
+                           (int)ncells, cell_of, counts);
+    else
+        hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, ndim, gl, cell_of,
+                           counts, list, list_count);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
+                       (unsigned long long *)nullptr, 0);
+    launch_scan_tail(ctx, counts, ncells, tile_sums, ntiles, start);
+    hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, ndim, gl,
+                       start, tsorted, list, list_count);
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
+static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim, const double *box, double per_cell,
+                       bool use_context_buffers, int level, int *level_extra, mm_knn_index **out,
+                       double *sparse_share = nullptr, bool stat_dirty = true, const GuessedBuild *guessed = nullptr)
+{
+    static_assert(kMaxLevels - 1 <= 8, "mm_buffer_slot reserves 8 pairs for the denser levels");
+    const int slot_cells = level == 0 ? (int)MM_BUF_CELL_START : (int)MM_BUF_LEVELS + 2 * (level - 1);
+    const int slot_xyz = level == 0 ? (int)MM_BUF_SORTED_XYZ : (int)MM_BUF_LEVELS + 2 * (level - 1) + 1;
+    *out = nullptr;
+    mm_knn_index *ix = new (std::nothrow) mm_knn_index();
+    if (!ix) {
+        mm_set_error(MM_ERR_ALLOC, "out of host memory");
+        return MM_ERR_ALLOC;
+    }
+    ix->nsrc = nsrc;
+    ix->ndim = ndim;
+    int live = 0;
+    grid_layout(box, nsrc, ndim, per_cell, ix, &live);
+    const i64 ncells = ix->ncells;
     const GridParams g = params_of(ix);
 
     // sorted_xyz holds nsrc + 1 records: the tile staging of the strip and cell kernels lets the lane of an
@@ -756,19 +788,15 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
             mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
             return MM_ERR_ALLOC;
         }
+        // the targets' counting sort.  (Round 4 also ran it AHEAD of a guessed call -- its grid is known before the centroids
+        // exist -- on a second stream beside the centroid kernel and the source sort: no gain, 3.51 vs 3.48 ms per step; they
+        // are all bandwidth-bound and simply share the HBM.)
         if (!(level == 0 && one_fill))
             if (mm_zero_async(ctx, counts, mm_fill_span((size_t)(ncells + 1) * sizeof(int))) != MM_OK) return MM_ERR_HIP;
-        if (!list && ncells <= kHistCells && npts >= 64 * ncells)   // many targets over few cells (see the kernel)
-            hipLaunchKernelGGL(cell_count_hist_kernel, dim3(256), dim3(kHistBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl,
-                               (int)ncells, cell_of, counts);
-        else
-            hipLaunchKernelGGL(cell_count_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, pts_d, npts, l->ndim, gl, cell_of,
-                               counts, list, list_count);
-        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(kBlock), 0, ctx->stream, counts, ncells, tile_sums,
-                           (unsigned long long *)nullptr, 0);
-        launch_scan_tail(ctx, counts, ncells, tile_sums, ntiles, start);
-        hipLaunchKernelGGL(target_scatter_kernel, dim3(gpts), dim3(kBlock), 0, ctx->stream, cell_of, npts, pts_d, l->ndim, gl,
-                           start, tsorted, list, list_count);
+        {
+            const int src_rc = sort_targets(ctx, gl, ncells, l->ndim, pts_d, npts, list, list_count, cell_of, counts, start, tile_sums, tsorted);
+            if (src_rc != MM_OK) return src_rc;
+        }
         if (lane_probe && level == 0) {
             // targets per occupied strip: the work-item count of the lane kernel's own prepass, read back once
             const int per_item = kWave * kLaneRounds;
