@@ -72,6 +72,11 @@ enum mm_buffer_slot {
     MM_BUF_L_W,
     MM_BUF_L_PTS,
     MM_BUF_LOC_SLOW,                      // locate stage: list of targets for the reference-order kernel + its counters
+    MM_BUF_TREE_KEYS,                     // the kNN tree (graded clouds): Morton keys, records, leaf levels, search table
+    MM_BUF_TREE_XYZ,
+    MM_BUF_TREE_LEVEL,
+    MM_BUF_TREE_COARSE,
+    MM_BUF_TREE_DOWN,                     //   ... targets of a query whose first window overflowed the tile (second pass)
     MM_BUF_LEVELS,                        // density levels of the kNN grid: {cell_start, sorted_xyz} per level
     MM_BUF_COUNT = MM_BUF_LEVELS + 2 * 8
 };
@@ -192,6 +197,18 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
 int mm_launch_gather(mm_context *ctx, const double *fields, i64 nsrc, i64 ncomp, const i64 *ids,
                      const double *w, i64 npoints, i64 P, double *out, int out_point_major);
 
+// The density-adaptive part of a kNN index (mm_knn_tree.inc.h): the sources in Morton order.
+struct mm_knn_tree {
+    double lo[3] = {0, 0, 0};      // corner of the bounding cube
+    double size = 1.0;             // its edge
+    double scale = 1.0;            // finest cells per unit length
+    unsigned long long *keys = nullptr;   // [nsrc] sorted Morton keys
+    double *xyz = nullptr;                // [nsrc + 1][4] records in that order
+    unsigned char *level = nullptr;       // [nsrc] level of the leaf around each source
+    int *coarse = nullptr;                // first source of every level-7 cell
+    bool borrowed = false;
+};
+
 // kNN search grid over source points (device resident).
 struct mm_knn_index {
     i64 nsrc = 0;
@@ -205,4 +222,6 @@ struct mm_knn_index {
     double *sorted_xyz = nullptr;  // [nsrc][4] records {x, y, z, original index bits} in cell order
     bool borrowed = false;         // arrays belong to the context's buffer cache (fused pipeline)
     mm_knn_index *fine = nullptr;  // next density level: a grid over the same sources with smaller cells (owned)
+    mm_knn_tree *tree = nullptr;   // graded clouds: the adaptive index that serves them instead of density levels (owned)
+    bool graded() const { return fine != nullptr || tree != nullptr; }
 };

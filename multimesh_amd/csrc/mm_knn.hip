@@ -26,11 +26,16 @@
 #include <cstring>
 
 int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums);
+// (mm_unique.hip: the stable LSD radix sort of 64-bit keys with 32-bit values)
+size_t mm_radix_sort_scratch(i64 n);
+int mm_radix_sort_pairs(mm_context *ctx, unsigned long long *ka, unsigned long long *kb, unsigned *va, unsigned *vb, i64 n,
+                        int first_shift, int end_shift, void *scratch, bool *in_a);
 
 namespace {
 #include "mm_knn_grid.inc.h"
 #include "mm_knn_rings.inc.h"
 #include "mm_knn_tiles.inc.h"
+#include "mm_knn_tree.inc.h"
 #include "mm_knn_lane.inc.h"
 
 // targets -> visiting order (counting sort by cell, same machinery as the source sort)
@@ -245,10 +250,23 @@ GridParams params_of(const mm_knn_index *ix)
     return g;
 }
 
+void free_tree(mm_knn_tree *tr)
+{
+    if (!tr) return;
+    if (!tr->borrowed) {
+        if (tr->keys) (void)mm_raw_free(tr->keys);
+        if (tr->xyz) (void)mm_raw_free(tr->xyz);
+        if (tr->level) (void)mm_raw_free(tr->level);
+        if (tr->coarse) (void)mm_raw_free(tr->coarse);
+    }
+    delete tr;
+}
+
 void free_index(mm_knn_index *ix)
 {
     if (!ix) return;
     free_index(ix->fine);
+    free_tree(ix->tree);
     if (!ix->borrowed) {
         if (ix->cell_start) (void)mm_raw_free(ix->cell_start);
         if (ix->sorted_xyz) (void)mm_raw_free(ix->sorted_xyz);
@@ -503,6 +521,9 @@ static int build_level(mm_context *ctx, const double *src_d, i64 nsrc, int ndim,
     return MM_OK;
 }
 
+static int tree_mode();
+static int tree_build(mm_context *ctx, mm_knn_index *ix, const double *src_d, i64 nsrc, const double *box, bool use_context_buffers);
+
 // Build without touching the stage timers (used by the fused pipeline too).
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
                       bool use_context_buffers, const double *box_partial_d, int box_nblocks)
@@ -562,6 +583,20 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         free_index(head);   // a large sparse region: cells of twice the volume
         head = nullptr;
         per_cell *= 2.0;
+    }
+    // a graded cloud: the adaptive index instead of a stack of denser grids (MM_KNN_TREE, see tree_mode)
+    {
+        const int mode = tree_mode();
+        bool cube = ndim == 3 && nsrc >= kLevelMinSources;
+        for (int a = 0; a < 3 && cube; ++a) cube = box[3 + a] - box[a] > 0.0 && isfinite(box[3 + a] - box[a]);
+        if (cube && (mode == 1 || (mode == -1 && (extra & (1 << (kMaxLevels - 2))) != 0 && max_levels > 1))) {
+            rc = tree_build(ctx, head, src_d, nsrc, box, use_context_buffers);
+            if (rc != MM_OK) {
+                free_index(head);
+                return rc;
+            }
+            extra = 0x10000;   // (no density levels; not a plain grid either: see grid_guess below)
+        }
     }
     mm_knn_index *tail = head;
     for (int l = 1; l < max_levels; ++l) {
@@ -623,13 +658,311 @@ bool mm_knn_guess_confirmed(mm_context *ctx)
     return extra == 0 && !(sparse_count / (double)ctx->grid_guess.nsrc > sparse_limit);
 }
 
+
+// ---- the density-adaptive index (mm_knn_tree.inc.h): build and query ----------------------------------------------
+static TreeParams tree_params_of(const mm_knn_tree *tr)
+{
+    TreeParams tp;
+    tp.lox = tr->lo[0];
+    tp.loy = tr->lo[1];
+    tp.loz = tr->lo[2];
+    tp.scale = tr->scale;
+    tp.size = tr->size;
+    return tp;
+}
+
+// MM_KNN_TREE: 0 = never (the stack of density levels only), 1 = for every 3-D cloud of at least kLevelMinSources sources
+// (tests, experiments), unset = where the stack ends: when the grid statistic of level 0 asks for the DEEPEST level the
+// stack can lay out (sources in cells of 256 x the design density and more -- the stack stops there, the tree does not).
+// Measured, round 4 (ms per pass; stack / tree): graded 10M hex8 mesh u^1.5 12.3 / 12.1, u^2.2 47.0 / 38.6; random 4M clouds,
+// k = 20, u^1.5 5.9 / 16.7, u^2 10.0 / 18.1, u^3 25.5 / 19.8; a 27 x refined region, k = 8: 3.4 / 5.4.  Read per call.
+static int tree_mode()
+{
+    const char *env = getenv("MM_KNN_TREE");
+    return env ? (atoi(env) == 0 ? 0 : 1) : -1;
+}
+
+// The sources in Morton order over the bounding cube of `box`: keys, records, leaf levels, the search table.
+static int tree_build(mm_context *ctx, mm_knn_index *ix, const double *src_d, i64 nsrc, const double *box,
+                      bool use_context_buffers)
+{
+    mm_knn_tree *tr = new (std::nothrow) mm_knn_tree();
+    if (!tr) {
+        mm_set_error(MM_ERR_ALLOC, "out of host memory");
+        return MM_ERR_ALLOC;
+    }
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        tr->lo[a] = box[a];
+        if (box[3 + a] - box[a] > ext) ext = box[3 + a] - box[a];
+    }
+    tr->size = ext * (1.0 + 0x1p-30);
+    tr->scale = (double)(1 << kTreeQ) / tr->size;
+    const size_t n_sz = (size_t)nsrc;
+    int rc = MM_OK;
+    if (use_context_buffers) {
+        tr->borrowed = true;
+        rc = mm_buffer_get(ctx, MM_BUF_TREE_KEYS, n_sz * sizeof(u64), (void **)&tr->keys);
+        if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_TREE_XYZ, (n_sz + 1) * kRec * sizeof(double), (void **)&tr->xyz);
+        if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_TREE_LEVEL, n_sz, (void **)&tr->level);
+        if (rc == MM_OK) rc = mm_buffer_get(ctx, MM_BUF_TREE_COARSE, (size_t)(kTreeCoarse + 2) * sizeof(int), (void **)&tr->coarse);
+    } else {
+        hipError_t e = mm_raw_alloc(ctx->device, (void **)&tr->keys, n_sz * sizeof(u64));
+        if (e == hipSuccess) e = mm_raw_alloc(ctx->device, (void **)&tr->xyz, (n_sz + 1) * kRec * sizeof(double));
+        if (e == hipSuccess) e = mm_raw_alloc(ctx->device, (void **)&tr->level, n_sz);
+        if (e == hipSuccess) e = mm_raw_alloc(ctx->device, (void **)&tr->coarse, (size_t)(kTreeCoarse + 2) * sizeof(int));
+        if (e != hipSuccess) {
+            mm_set_error(MM_ERR_ALLOC, "kNN tree allocation failed: %s", hipGetErrorString(e));
+            rc = MM_ERR_ALLOC;
+        }
+    }
+    if (rc != MM_OK) {
+        free_tree(tr);
+        return rc;
+    }
+    const size_t need = mm_round256(n_sz * sizeof(u64)) + 2 * mm_round256(n_sz * sizeof(unsigned)) + mm_radix_sort_scratch(nsrc) + 1024;
+    rc = mm_scratch_begin(ctx, need);
+    if (rc != MM_OK) {
+        free_tree(tr);
+        return rc;
+    }
+    u64 *key_b = (u64 *)mm_scratch_take(ctx, n_sz * sizeof(u64));
+    unsigned *val_a = (unsigned *)mm_scratch_take(ctx, n_sz * sizeof(unsigned));
+    unsigned *val_b = (unsigned *)mm_scratch_take(ctx, n_sz * sizeof(unsigned));
+    void *radix = mm_scratch_take(ctx, mm_radix_sort_scratch(nsrc));
+    if (!key_b || !val_a || !val_b || !radix) {
+        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+        free_tree(tr);
+        return MM_ERR_ALLOC;
+    }
+    const TreeParams tp = tree_params_of(tr);
+    const unsigned gsrc = (unsigned)((nsrc + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(tree_keys_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, nsrc, 3, 3, tp, (const int *)nullptr,
+                       (const int *)nullptr, tr->keys, val_a);
+    bool in_a = true;
+    static_assert((kTreeBits / 8) % 2 == 0 && kTreeBits % 8 == 0, "an even number of 8-bit passes: the sorted keys end where they started");
+    rc = mm_radix_sort_pairs(ctx, tr->keys, key_b, val_a, val_b, nsrc, 0, kTreeBits, radix, &in_a);
+    if (rc != MM_OK || !in_a) {
+        if (rc == MM_OK) mm_set_error(MM_ERR_HIP, "kNN tree: the sort ended in the wrong buffer");
+        free_tree(tr);
+        return rc != MM_OK ? rc : MM_ERR_HIP;
+    }
+    hipLaunchKernelGGL(tree_records_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, src_d, 3, 3, val_a, nsrc, (const int *)nullptr, tr->xyz);
+    hipLaunchKernelGGL(tree_coarse_kernel, dim3((kTreeCoarse + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, tr->keys,
+                       (int)nsrc, tr->coarse);
+    hipLaunchKernelGGL(tree_leaf_level_kernel, dim3(gsrc), dim3(kBlock), 0, ctx->stream, tr->keys, nsrc, tr->level);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mm_set_error(MM_ERR_HIP, "kNN tree build launch: %s", hipGetErrorString(e));
+        free_tree(tr);
+        return MM_ERR_HIP;
+    }
+    ix->tree = tr;
+    return MM_OK;
+}
+
+// The single-target search of a tree query.  A lane of tree_ring_kernel walks a chain of ~10^3 dependent loads (searches on
+// the keys, then the runs): 1 - 2 ms per target whatever the list's length -- hidden when hundreds of thousands of targets
+// fill the chip (6 ns per target), all there is to see when the list holds a few thousand.  Lists up to kTreeWaveListMax
+// therefore take one WAVE per target over the level-0 grid (knn_list_wave_kernel: no searches, 64 lanes per block of cells).
+// Both kernels are launched; each returns at once when the length is on the other's side.
+constexpr int kTreeWaveListMax = 65536;
+template <typename IDX>
+static void tree_ring(mm_context *ctx, const mm_knn_index *ix, const double *pts, int pstride, i64 npts, int kout, IDX *idx_d,
+                      double *dist_d, const int *list, const int *list_count)
+{
+    const mm_knn_tree *tr = ix->tree;
+    i64 grid = (npts + kBlock - 1) / kBlock;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    LevelTable lv;
+    lv.n = 1;
+    lv.g[0] = params_of(ix);
+    lv.cell_start[0] = ix->cell_start;
+    lv.sorted_xyz[0] = ix->sorted_xyz;
+    const i64 wgrid = npts < 8192 ? (npts > 0 ? npts : 1) : 8192;
+#define MM_TREE_RING(KK)                                                                                                           \
+    do {                                                                                                                           \
+        hipLaunchKernelGGL((knn_list_wave_kernel<KK, IDX>), dim3((unsigned)wgrid), dim3(kWave), 0, ctx->stream, lv, ix->nsrc, pts, \
+                           ix->ndim, pstride, kout, idx_d, dist_d, list, list_count, kListKeepMax, kTreeWaveListMax,               \
+                           (const int *)nullptr);                                                                                  \
+        if (npts > kTreeWaveListMax)                                                                                               \
+            hipLaunchKernelGGL((tree_ring_kernel<KK, IDX>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream,                    \
+                               tree_params_of(tr), (const u64 *)tr->keys, (const int *)tr->coarse,                                 \
+                               (const unsigned char *)tr->level, (const double *)tr->xyz, (int)ix->nsrc, pts, ix->ndim, pstride,   \
+                               kout, idx_d, dist_d, list, list_count, kTreeWaveListMax);                                           \
+    } while (0)
+    if (kout <= 1) MM_TREE_RING(1);
+    else if (kout <= 2) MM_TREE_RING(2);
+    else if (kout <= 4) MM_TREE_RING(4);
+    else if (kout <= 8) MM_TREE_RING(8);
+    else if (kout <= 16) MM_TREE_RING(16);
+    else MM_TREE_RING(20);
+#undef MM_TREE_RING
+}
+
+// lists shorter than this go straight to the ring search (sparse targets fill no 64-lane rounds)
+constexpr i64 kTreeRingListMax = 8192;
+
+// A query through the tree: the targets (all of them, or those of a device-side list whose length list_len the caller has
+// read back) in Morton order, one work item per run of at most 256 targets of one node, the lane kernel's TREE
+// instantiation, and the ring search over the level-0 grid for what it hands over.  Rows by the targets' own index, or --
+// tsorted_out, no list -- by their position in the sorted order, which the caller receives.
+template <typename IDX>
+static int tree_query(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, int kout, IDX *idx_d,
+                      double *dist_d, const double **tsorted_out, const int *list, const int *list_count, i64 list_len,
+                      int pstride = 0, bool second_pass = false)
+{
+    // second_pass: the targets of this very query that its first windows did not serve -- they held more sources than the
+    // tile (the expected load of a window assumes the node's density around it; a lattice of lines or sheets, anisotropic
+    // elements, can hold several times that), or the k-th neighbour lay beyond the margin --: once more, with wider margins
+    // and windows laid out for 70 % of the load.  What fails again goes to the single-target search.
+    if (pstride == 0) pstride = ix->ndim;
+    const mm_knn_tree *tr = ix->tree;
+    const i64 n = list ? list_len : npts;
+    if (n <= 0) return MM_OK;
+    if (list && n < kTreeRingListMax) {
+        tree_ring<IDX>(ctx, ix, pts_d, pstride, n, kout, idx_d, dist_d, list, list_count);
+        MM_HIP_CHECK(hipGetLastError());
+        return MM_OK;
+    }
+    const size_t n_sz = (size_t)n;
+    static const bool unsorted_rows = getenv("MM_KNN_UNSORTED_ROWS") != nullptr;
+    const bool sorted_rows = !list && tsorted_out != nullptr && !unsorted_rows;
+    const int scan_tiles = (int)((n + 1 + kScanTile - 1) / kScanTile);
+    const size_t need = 2 * mm_round256(n_sz * sizeof(u64)) + 2 * mm_round256(n_sz * sizeof(unsigned)) + mm_radix_sort_scratch(n) +
+                        2 * mm_round256((n_sz + 1) * sizeof(int)) + mm_round256((size_t)scan_tiles * sizeof(int)) +
+                        mm_round256((n_sz + 1) * sizeof(TreeItem)) + (sorted_rows ? 0 : mm_round256(n_sz * kRec * sizeof(double))) +
+                        mm_round256((size_t)npts * sizeof(int)) + 256 + 4096;
+    int rc = mm_scratch_begin(ctx, need);
+    if (rc != MM_OK) return rc;
+    u64 *key_a = (u64 *)mm_scratch_take(ctx, n_sz * sizeof(u64));
+    u64 *key_b = (u64 *)mm_scratch_take(ctx, n_sz * sizeof(u64));
+    unsigned *val_a = (unsigned *)mm_scratch_take(ctx, n_sz * sizeof(unsigned));
+    unsigned *val_b = (unsigned *)mm_scratch_take(ctx, n_sz * sizeof(unsigned));
+    void *radix = mm_scratch_take(ctx, mm_radix_sort_scratch(n));
+    int *flag = (int *)mm_scratch_take(ctx, (n_sz + 1) * sizeof(int));
+    int *rank = (int *)mm_scratch_take(ctx, (n_sz + 1) * sizeof(int));
+    int *scan_sums = (int *)mm_scratch_take(ctx, (size_t)scan_tiles * sizeof(int));
+    TreeItem *items = (TreeItem *)mm_scratch_take(ctx, (n_sz + 1) * sizeof(TreeItem));
+    int *fb_list = (int *)mm_scratch_take(ctx, (size_t)npts * sizeof(int));
+    int *fb_count = (int *)mm_scratch_take(ctx, 256);   // [0] hand-overs, [1] work items, [2] of the hand-overs: by overflow, [3] passed to the second pass
+    int *down_list = nullptr;
+    if (!second_pass) {
+        // (outlives this pass's scratch: the second pass carves the pool anew)
+        rc = mm_buffer_get(ctx, MM_BUF_TREE_DOWN, (n_sz + 64) * sizeof(int), (void **)&down_list);   // (the list, then its length)
+        if (rc != MM_OK) return rc;
+    }
+    double *tsorted = nullptr;
+    if (sorted_rows) {
+        // (outlives this call's scratch: the locate stage reads it)
+        rc = mm_buffer_get(ctx, MM_BUF_TSORTED, (size_t)npts * kRec * sizeof(double), (void **)&tsorted);
+        if (rc != MM_OK) return rc;
+    } else {
+        tsorted = (double *)mm_scratch_take(ctx, n_sz * kRec * sizeof(double));
+    }
+    if (!key_a || !key_b || !val_a || !val_b || !radix || !flag || !rank || !scan_sums || !items || !fb_list || !fb_count || !tsorted) {
+        mm_set_error(MM_ERR_ALLOC, "scratch carve failed");
+        return MM_ERR_ALLOC;
+    }
+    if ((rc = mm_zero_async(ctx, fb_count, 256)) != MM_OK) return rc;
+    const TreeParams tp = tree_params_of(tr);
+    const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(tree_keys_kernel, dim3(gn), dim3(kBlock), 0, ctx->stream, pts_d, n, ix->ndim, pstride, tp, list, list_count, key_a, val_a);
+    bool in_a = true;
+    rc = mm_radix_sort_pairs(ctx, key_a, key_b, val_a, val_b, n, 0, kTreeBits, radix, &in_a);
+    if (rc != MM_OK) return rc;
+    const u64 *tkeys = in_a ? key_a : key_b;
+    const unsigned *tvals = in_a ? val_a : val_b;
+    u64 *node = in_a ? key_b : key_a;   // (the sort's other buffer is free now)
+    hipLaunchKernelGGL(tree_records_kernel, dim3(gn), dim3(kBlock), 0, ctx->stream, pts_d, ix->ndim, pstride, tvals, n, list_count, tsorted);
+    // (MM_TREE_CELL_MIN / MM_TREE_TILE_MAX: tuning experiments only)
+    static const int env_cell_min = getenv("MM_TREE_CELL_MIN") ? atoi(getenv("MM_TREE_CELL_MIN")) : 0;
+    static const int env_tile_max = getenv("MM_TREE_TILE_MAX") ? atoi(getenv("MM_TREE_TILE_MAX")) : 0;
+    static const int env_cell_min2 = getenv("MM_TREE_CELL_MIN2") ? atoi(getenv("MM_TREE_CELL_MIN2")) : 0;
+    static const int env_tile_max2 = getenv("MM_TREE_TILE_MAX2") ? atoi(getenv("MM_TREE_TILE_MAX2")) : 0;
+    int cell_min = env_cell_min > 0 ? (kout <= 8 ? env_cell_min : (env_cell_min * 5 + 1) / 2) : tree_cell_min(kout);
+    int tile_max = env_tile_max > 0 ? env_tile_max : kTreeTileMax;
+    if (second_pass) {
+        // what the first windows could not serve -- too full for the tile, or a k-th neighbour beyond the margin --: margins
+        // of ~1.8 local spacings instead of ~1.3 (cells of 3 x the sources), laid out for 70 % of the tile
+        cell_min = env_cell_min2 > 0 ? env_cell_min2 : (kout <= 8 ? 3 * cell_min : (3 * cell_min) / 2);
+        tile_max = env_tile_max2 > 0 ? env_tile_max2 : (7 * tile_max) / 10;
+    }
+    hipLaunchKernelGGL(tree_target_node_kernel, dim3(gn), dim3(kBlock), 0, ctx->stream, tkeys, n, list_count, tr->keys,
+                       (int)ix->nsrc, tr->coarse, tr->level, cell_min, tile_max, node);
+    hipLaunchKernelGGL(tree_item_flags_kernel, dim3(gn), dim3(kBlock), 0, ctx->stream, node, n, list_count, kWave * kLaneRounds, flag);
+    if ((rc = mm_exclusive_scan_int(ctx, flag, n, rank, scan_sums)) != MM_OK) return rc;
+    int *nitems_d = fb_count + 1;
+    hipLaunchKernelGGL(tree_items_kernel, dim3(gn), dim3(kBlock), 0, ctx->stream, node, n, list_count, flag, rank, tr->keys,
+                       (int)ix->nsrc, tr->coarse, items, nitems_d);
+    // the number of work items sizes the launch: one small wait (a graded cloud's pass takes milliseconds)
+    MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 2, nitems_d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const i64 nitems = (i64) * reinterpret_cast<const int *>(ctx->h_counters + 2);
+    if (nitems > 0) {
+        TreeArgs ta;
+        ta.tp = tp;
+        ta.keys = tr->keys;
+        ta.coarse = tr->coarse;
+        ta.items = items;
+        ta.nitems = nitems_d;
+        const unsigned wgs = (unsigned)(8 * (nitems / 8 + 1));
+        const GridParams g = params_of(ix);
+        const int T = kLaneThin;
+        if (!list) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
+#define MM_TREE_LANE(KK)                                                                                                          \
+    hipLaunchKernelGGL((knn_lane_kernel<KK, IDX, true>), dim3(wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc, (const int *)nullptr, \
+                       (const double *)tr->xyz, ix->ndim, kout, (const int *)nullptr, (const double *)tsorted, idx_d, dist_d,      \
+                       fb_list, fb_count, (const int2 *)nullptr, 0, 1, kWave * kLaneRounds, sorted_rows ? 1 : 0, down_list,        \
+                       down_list ? fb_count + 3 : (int *)nullptr, T, KK <= 8 ? kLaneWin : T, ta)
+        if (kout <= 1) MM_TREE_LANE(1);
+        else if (kout <= 2) MM_TREE_LANE(2);
+        else if (kout <= 4) MM_TREE_LANE(4);
+        else if (kout <= 8) MM_TREE_LANE(8);
+        else if (kout <= 16) MM_TREE_LANE(16);
+        else MM_TREE_LANE(20);
+#undef MM_TREE_LANE
+        if (!list) mm_stage_end(ctx, MM_STAGE_KNN_CELL);
+    }
+    MM_HIP_CHECK(hipGetLastError());
+    static const bool dbg_query = getenv("MM_KNN_DEBUG") != nullptr;
+    if (dbg_query) {
+        int h[4] = {0, 0, 0, 0};
+        MM_HIP_CHECK(hipMemcpyAsync(h, fb_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[mm_knn] tree%s: %lld targets in %lld work items, %d handed to the single-target search (%d of them by windows "
+                        "too full for the tile), %d to a second pass; k = %d\n", second_pass ? " (second pass)" : "", (long long)n,
+                (long long)nitems, h[0], h[2], h[3], kout);
+    }
+    // what the windows could not certify: the tree's own ring search (cells of the target's node size, then coarser)
+    tree_ring<IDX>(ctx, ix, sorted_rows ? (const double *)tsorted : pts_d, sorted_rows ? kRec : pstride, npts, kout, idx_d, dist_d,
+                   fb_list, fb_count);
+    MM_HIP_CHECK(hipGetLastError());
+    if (down_list && nitems > 0) {
+        // windows too full for the tile: their targets once more (rows as in this pass: by sorted position or own index)
+        MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 2, fb_count + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const i64 n2 = (i64) * reinterpret_cast<const int *>(ctx->h_counters + 2);
+        if (n2 > 0) {
+            int *count2 = down_list + n_sz;   // (out of the scratch pool, with the list)
+            MM_HIP_CHECK(hipMemcpyAsync(count2, fb_count + 3, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            const int rc2 = tree_query<IDX>(ctx, ix, sorted_rows ? (const double *)tsorted : pts_d, npts, kout, idx_d, dist_d, nullptr,
+                                            down_list, count2, n2, sorted_rows ? kRec : pstride, true);
+            if (rc2 != MM_OK) return rc2;
+        }
+    }
+    if (sorted_rows) *tsorted_out = tsorted;
+    return MM_OK;
+}
+
 // tsorted_out (nullable): the caller can take the rows in the cell-sorted order of the targets; on return
 // *tsorted_out = the sorted target records {x, y, z, index} (context buffer, valid until the next query) when the
 // rows were written in that order, null when they are in the targets' own order (paths without the lane kernel).
 template <typename IDX>
 static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, IDX *idx_d,
                            double *dist_d, const double **tsorted_out, const int *list0 = nullptr,
-                           const int *list0_count = nullptr)
+                           const int *list0_count = nullptr, i64 list0_len = -1)
 {
     // list0 (device): only the targets list0[0 .. *list0_count) are served (rows by the targets' own indices as ever);
     // the tiled kernels then walk just the strips that hold any of them (k <= 32)
@@ -638,6 +971,9 @@ static int knn_query_typed(mm_context *ctx, const mm_knn_index *ix, const double
     MM_REQUIRE(npts < (i64)0x7fffffff, "too many targets for one query");
     const GridParams g = params_of(ix);
     const int kout = (int)k;
+    // a graded cloud with the adaptive index (lists the lane kernel can hold; a list only when its length is known here)
+    if (ix->tree && k <= kLaneMaxK && (!list0 || list0_len >= 0) && !getenv("MM_KNN_FORCE_LIST"))
+        return tree_query<IDX>(ctx, ix, pts_d, npts, kout, idx_d, dist_d, tsorted_out, list0, list0_count, list0_len);
     if (k > 32) {
         // long lists: generic ring-expansion kernel for every target (in the grid that suits it, when
         // the cloud has density levels)
@@ -877,7 +1213,8 @@ int mm_knn_query_list_impl(mm_context *ctx, const mm_knn_index *ix, const double
     // strips that hold listed targets -- the list-mode kernels below serve one target per lane or per wave, which is
     // right for the stragglers of a uniform mesh and 5-10x too slow for a million targets.  (The caller must not keep
     // anything in the context's scratch pool across this call: the cascade carves it anew.)
-    if (list_len_hint >= kLongListMin && k <= 32) return knn_query_typed<int>(ctx, ix, pts_d, npts, k, idx_d, nullptr, nullptr, list, list_count);
+    if ((list_len_hint >= kLongListMin || (ix->tree && list_len_hint >= 0)) && k <= 32)
+        return knn_query_typed<int>(ctx, ix, pts_d, npts, k, idx_d, nullptr, nullptr, list, list_count, list_len_hint);
     LevelTable lv;
     lv.n = 0;
     for (const mm_knn_index *l = ix; l && lv.n < kMaxLevels; l = l->fine) {

@@ -193,7 +193,9 @@ __device__ __forceinline__ void lane_list_insert(float (&d)[L], float c, float n
     d[0] = __builtin_amdgcn_fmed3f(neg_inf, c, d[0]);
 }
 
-template <int K, typename IDX>
+// TREE: the work items, their windows and the faces of the certificate come from the density-adaptive index
+// (mm_knn_tree.inc.h) instead of the uniform grid g; everything from the staged tile on is the same code.
+template <int K, typename IDX, bool TREE = false>
 __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 nsrc, const int *__restrict__ cell_start,
                                                             const double *__restrict__ sorted_xyz, int ndim, int kout,
                                                             const int *__restrict__ tstart,
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                                                             int *__restrict__ fb_count, const int2 *__restrict__ items,
                                                             int nslots, int Z, int per_item, int sorted_rows,
                                                             int *__restrict__ down_list, int *__restrict__ down_count,
-                                                            int T, int W)
+                                                            int T, int W, TreeArgs ta = TreeArgs())
 {
     // sorted_rows: a target's row goes to its position in the cell-sorted order (the fused pipeline's locate
     // stage then walks the targets in that order: rows and coordinates stream, neighbours share elements) and
@@ -229,6 +231,62 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
     {
         // ONE work item per workgroup (the grid is the slot count): no loop around the item, so nothing the early
         // phases need -- pointers, extents -- has to stay in scalar registers for a next trip
+        // (tree_* : the window of a tree item -- cells of level tree_lc and edge tree_c, tree_nax/y/z per axis, the first one at
+        // (tree_bx, tree_by, tree_bz); unused otherwise)
+        int tree_lc = 0, tree_nax = 0, tree_nay = 0, tree_naz = 0, tree_bx = 0, tree_by = 0, tree_bz = 0;
+        double tree_c = 0.0;
+        int cx = 0, cy = 0, cz0 = 0, za = 0, zb = 0, nlayers, t0, tn;
+        constexpr int NB = TREE ? 4 : 2;   // cells per lane (6^3 = 216 cells in the largest tree window)
+        int s0[NB], cnt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s0[b] = cnt[b] = 0;
+        double ox, oy, oz;
+        if (TREE) {
+            // item q of the list (Morton order) is taken by workgroup 8 m + x, x = the eighth of the list it lies in: the
+            // slot rule of the uniform kernel, worked out here from the item count on the device
+            const int total = *ta.nitems;
+            const int x8 = (int)blockIdx.x & 7, m8 = (int)blockIdx.x >> 3;
+            const i64 q0 = ((i64)total * x8) >> 3, q1 = ((i64)total * (x8 + 1)) >> 3;
+            if (q0 + m8 >= q1) return;
+            const TreeItem it = ta.items[q0 + m8];
+            t0 = it.t0;
+            tn = ta.items[q0 + m8 + 1].t0 - t0;
+            // the node: P leading key bits -- the octree cell of level P / 3, halved along z (P % 3 >= 1) and y (P % 3 == 2);
+            // its window: one cell of level P / 3 + d around it (mm_knn_tree.inc.h)
+            const int P = (int)((it.node >> kTreeLevelShift) & 0x3f), deeper = (int)(it.node >> 62);
+            const u64 k0n = it.node & ((1ull << kTreeLevelShift) - 1ull);
+            tree_lc = P / 3 + deeper;
+            const int shq = kTreeQ - tree_lc;
+            // (the node's first key is its corner: the low bits are zero)
+            tree_bx = (int)(tree_compact3(k0n) >> shq) - 1;
+            tree_by = (int)(tree_compact3(k0n >> 1) >> shq) - 1;
+            tree_bz = (int)(tree_compact3(k0n >> 2) >> shq) - 1;
+            const int jj = P - 3 * (P / 3), aa = 1 << deeper;
+            tree_nax = aa + 2;
+            tree_nay = (jj >= 2 ? aa >> 1 : aa) + 2;
+            tree_naz = (jj >= 1 ? aa >> 1 : aa) + 2;
+            tree_c = ta.tp.size / (double)(1 << tree_lc);
+            nlayers = tree_naz;
+            // ---- extents of the window's cells, up to four per lane: two searches on the sorted keys each
+            const int ncl = 1 << tree_lc;
+            const int sh = 3 * shq;
+            const int wcells = tree_nax * tree_nay * tree_naz;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int q = lane + 64 * b;
+                const int iz = q / (tree_nax * tree_nay), r2 = q - iz * tree_nax * tree_nay, iy = r2 / tree_nax, ix = r2 - iy * tree_nax;
+                const int gx = tree_bx + ix, gy = tree_by + iy, gz = tree_bz + iz;
+                if (q < wcells && (unsigned)gx < (unsigned)ncl && (unsigned)gy < (unsigned)ncl && (unsigned)gz < (unsigned)ncl) {
+                    const u64 k0 = tree_morton((unsigned)gx, (unsigned)gy, (unsigned)gz) << sh;
+                    s0[b] = tree_lower_bound(ta.keys, ta.coarse, (int)nsrc, k0);
+                    cnt[b] = min(tree_lower_bound(ta.keys, ta.coarse, (int)nsrc, k0 + (1ull << sh)) - s0[b], kLaneTileCap + 1);
+                }
+            }
+            // (the tile's frame: the corner of the cell behind the window's first one, i.e. the node's own corner)
+            ox = ta.tp.lox + (double)(tree_bx + 1) * tree_c;
+            oy = ta.tp.loy + (double)(tree_by + 1) * tree_c;
+            oz = ta.tp.loz + (double)(tree_bz + 1) * tree_c;
+        } else {
         if ((int)blockIdx.x >= nslots) return;
         const int2 item = items[blockIdx.x];
         if (item.x < 0) return;
@@ -237,13 +295,15 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 #endif
         MM_STAMP(0);   // kernel start / previous item -> item descriptor here
         const int col = item.x / nstrips, strip = item.x - col * nstrips;
-        const int cx = col / g.ny, cy = col - cx * g.ny;
-        const int cz0 = strip * Z, cz1 = min(cz0 + Z, g.nz);
-        const int za = max(cz0 - 1, 0), zb = min(cz1, g.nz - 1);
-        const int nlayers = zb - za + 1;
+        cx = col / g.ny;
+        cy = col - cx * g.ny;
+        cz0 = strip * Z;
+        const int cz1 = min(cz0 + Z, g.nz);
+        za = max(cz0 - 1, 0);
+        zb = min(cz1, g.nz - 1);
+        nlayers = zb - za + 1;
         const int ntc = nlayers * 9;                      // <= (kLaneZMax + 2) * 9 = 126 cells: two per lane
         // ---- extents of the tile's cells (cell q = 9 * layer + column), two per lane
-        int s0[2] = {0, 0}, cnt[2] = {0, 0};
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int q = lane + 64 * b;
@@ -257,13 +317,14 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 cnt[b] = min(cell_start[cellid + 1] - s0[b], kLaneTileCap + 1);
             }
         }
-        int t0 = tstart[col * g.nz + cz0];
+        t0 = tstart[col * g.nz + cz0];
         const int t1 = tstart[col * g.nz + cz1];
         t0 += item.y * per_item;
-        const int tn = min(per_item, t1 - t0);            // this item's share of the strip's targets
-        const double ox = g.lox + (double)cx * g.hx;
-        const double oy = g.loy + (double)cy * g.hy;
-        const double oz = g.loz + (double)cz0 * g.hz;
+        tn = min(per_item, t1 - t0);            // this item's share of the strip's targets
+        ox = g.lox + (double)cx * g.hx;
+        oy = g.loy + (double)cy * g.hy;
+        oz = g.loz + (double)cz0 * g.hz;
+        }
         // the first round's targets: in flight while the tile is staged
         double npx, npy, npz, npw;
         {
@@ -275,8 +336,17 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             npw = zw.y;
         }
         // ---- natural tile offsets: prefix sum over the cells in (layer, column) order
-        int nat[2], nat_total;
-        {
+        int nat[NB], nat_total;
+        if (TREE) {
+            int lane_total = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) lane_total += cnt[b];
+            const int incl = wave_inclusive_sum(lane_total);
+            nat_total = __builtin_amdgcn_readlane(incl, kWave - 1);
+            nat[0] = incl - lane_total;
+#pragma unroll
+            for (int b = 1; b < NB; ++b) nat[b] = nat[b - 1] + cnt[b - 1];
+        } else {
             // (both prefix sums in one word -- a tile holds < 2^16 sources and the counts are clamped --: six dependent
             // shuffles instead of twelve; unsigned, so that the upper sum may use all of its 16 bits)
             const unsigned packed = (unsigned)wave_inclusive_sum((int)((unsigned)cnt[0] | ((unsigned)cnt[1] << 16)));
@@ -289,6 +359,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
 #ifdef MM_LANE_STAMPS
         asm volatile("" ::"v"(nat[0]), "v"(nat[1]));
 #endif
+        if (TREE) nat_total = min(nat_total, kLaneTileCap + 1);   // (the sum of clamped counts: any overflow reads as one)
         MM_STAMP(1);   // cell extents arrived, offsets computed
         if (nat_total > kLaneTileCap) {
             // too full for the tile (a locally much denser region): the item's targets go to the next density
@@ -297,9 +368,11 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             if (down_list) {
                 if (lane == 0) base = atomicAdd(down_count, tn);
                 base = __shfl(base, 0);
-                for (int q = lane; q < tn; q += kWave) down_list[base + q] = record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
+                for (int q = lane; q < tn; q += kWave)
+                    down_list[base + q] = TREE && sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
             } else {
                 if (lane == 0) base = atomicAdd(fb_count, tn);
+                if (TREE && lane == 0) atomicAdd(fb_count + 2, tn);   // (diagnostic: hand-overs by overflow)
                 base = __shfl(base, 0);
                 for (int q = lane; q < tn; q += kWave)
                     fb_list[base + q] = sorted_rows ? t0 + q : record_id(tsorted[(i64)(t0 + q) * kRec + 3]);
@@ -308,7 +381,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         }
         // ---- stage, step 1: every entry's position in the sorted array, in cell order (the cells' owners know them) ...
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
             for (int q = 0; q < cnt[b]; ++q) reinterpret_cast<int *>(tile + nat[b] + q)[3] = s0[b] + q;
         s_hist[lane] = 0;
         wave_sync();
@@ -321,9 +394,9 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
         // and candidates are what the scan's vector instructions are spent on).  The rank inside the thin layer
         // comes back from the LDS atomic that counts it.
         const int NL = nlayers * T;                              // <= kLaneThinMax (the launcher checks)
-        const float zbase = (float)((double)(za - cz0) * g.hz);  // z of the tile's bottom, relative to the strip corner
-        const double th = g.hz / (double)T;                      // thickness of a thin layer
-        const float inv_t = (float)((double)T * g.ihz);
+        const float zbase = TREE ? (float)(-tree_c) : (float)((double)(za - cz0) * g.hz);  // z of the tile's bottom, relative to the strip corner
+        const double th = (TREE ? tree_c : g.hz) / (double)T;    // thickness of a thin layer
+        const float inv_t = TREE ? (float)((double)T / tree_c) : (float)((double)T * g.ihz);
         {
             // (everything a lane holds of the tile stays in registers between the two LDS phases: the entries cannot be
             // parked in their cell-order slots, which the final order overwrites)
@@ -543,8 +616,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             hand_over = !finite || !(kth < INFINITY);
             {
                 // every source outside the list lies at an exact distance >= lb (header comment)
-                const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) + 2.0 * (g.hx + g.hy) +
-                                             (double)(Z + 1) * g.hz);
+                const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) +
+                                             (TREE ? 12.0 * tree_c : 2.0 * (g.hx + g.hy) + (double)(Z + 1) * g.hz));
                 const float B = d[L - 1];
                 if (B < kLaneFarKey) {
                     // (v_sqrt_f32 is within 1 ulp: 2^-21 more off the factor covers it)
@@ -554,19 +627,35 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
                 // could a nearer source sit outside what was scanned?  Beyond the x / y faces of the 3 x 3 columns
                 // (as block_bound: faces that still have cells behind them) ...
                 double bound = INFINITY;
+                bool below, above;   // cells under / over the tile
+                if (TREE) {
+                    // the window's faces in x and y (those with cells of the cube behind them); a source of a cell beyond a
+                    // face has a coordinate beyond it up to the rounding of tree_quant's product (< 1e-10 of a cell edge)
+                    const double slack = 1e-9 * tree_c;
+                    const int ncl = 1 << tree_lc;
+                    if (tree_bx > 0) bound = fmin(bound, (px - (ta.tp.lox + (double)tree_bx * tree_c)) - slack);
+                    if (tree_bx + tree_nax < ncl) bound = fmin(bound, ((ta.tp.lox + (double)(tree_bx + tree_nax) * tree_c) - px) - slack);
+                    if (tree_by > 0) bound = fmin(bound, (py - (ta.tp.loy + (double)tree_by * tree_c)) - slack);
+                    if (tree_by + tree_nay < ncl) bound = fmin(bound, ((ta.tp.loy + (double)(tree_by + tree_nay) * tree_c) - py) - slack);
+                    below = tree_bz > 0;
+                    above = tree_bz + tree_naz < ncl;
+                } else {
                 const double slack_x = 1e-9 * g.hx, slack_y = 1e-9 * g.hy;
                 if (cx - 1 > 0) bound = fmin(bound, (px - (g.lox + (double)(cx - 1) * g.hx)) - slack_x);
                 if (cx + 1 < g.nx - 1) bound = fmin(bound, ((g.lox + (double)(cx + 2) * g.hx) - px) - slack_x);
                 if (cy - 1 > 0) bound = fmin(bound, (py - (g.loy + (double)(cy - 1) * g.hy)) - slack_y);
                 if (cy + 1 < g.ny - 1) bound = fmin(bound, ((g.loy + (double)(cy + 2) * g.hy) - py) - slack_y);
+                below = za > 0;
+                above = zb < g.nz - 1;
+                }
                 // ... or in a thin layer below / above the window.  The planes between thin layers are taken in the
                 // tile's fp32 frame, where the sources were binned: a source outside the window has an fp32 z beyond
                 // the plane (the bin arithmetic is off by < 1e-5 of a thin layer), its coordinate and the target's
                 // are within E of the exact ones.  A clipped window ends at the tile's own face, which has sources
                 // behind it unless it is the grid's.
                 const double zs = E + 1e-4 * th;
-                if (lo > 0 || za > 0) bound = fmin(bound, ((double)tz - ((double)zbase + (double)lo * th)) - zs);
-                if (hi < NL - 1 || zb < g.nz - 1) bound = fmin(bound, (((double)zbase + (double)(hi + 1) * th) - (double)tz) - zs);
+                if (lo > 0 || below) bound = fmin(bound, ((double)tz - ((double)zbase + (double)lo * th)) - zs);
+                if (hi < NL - 1 || above) bound = fmin(bound, (((double)zbase + (double)(hi + 1) * th) - (double)tz) - zs);
                 if (bound < INFINITY && !(bound > 0.0 && kth < bound * bound)) hand_over = true;
             }
             if (!kRetry || attempt > 0 || W >= T || !__any(valid && hand_over)) break;
@@ -650,9 +739,12 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             if (mf) {
                 const int firstl = __ffsll((long long)mf) - 1;
                 int base = 0;
-                if (lane == firstl) base = atomicAdd(fb_count, __popcll(mf));
+                // (a tree query's first pass: to the second pass, whose windows are laid out with wider margins)
+                int *const out_list = TREE && down_list ? down_list : fb_list;
+                int *const out_count = TREE && down_list ? down_count : fb_count;
+                if (lane == firstl) base = atomicAdd(out_count, __popcll(mf));
                 base = __shfl(base, firstl);
-                if (valid && hand_over) fb_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)i;
+                if (valid && hand_over) out_list[base + __popcll(mf & ((1ull << lane) - 1ull))] = (int)i;
             }
             if (kRowsInLds) wave_sync();   // rows are rewritten by the next round
             MM_STAMP(6);   // ranks, certification, output

@@ -874,7 +874,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         dim3 g_((unsigned)grid), b_(block);
         // (walk order of the sorted targets: see the kernel; the kNN grid's x dimension comes with the lazy lists)
         static const int panel_env = getenv("MM_LOCATE_PANEL") ? atoi(getenv("MM_LOCATE_PANEL")) : kPassPanel;
-        const int planes = (tsorted && lazy && lazy->index && !lazy->index->fine) ? lazy->index->dims[0] : 0;
+        const int planes = (tsorted && lazy && lazy->index && !lazy->index->graded()) ? lazy->index->dims[0] : 0;
         const int panel = panel_env;   // (0: in order, < 0: the kernel's default)
         hipLaunchKernelGGL(first_fn, g_, b_, 0, ctx->stream, k, npoints, nn, conn, nelem, em, nodes, tsorted ? tsorted : pts,
                            slow, slow_count, (const int *)nullptr, (const int *)nullptr, 0, planes, panel, unsure_count,
@@ -892,7 +892,7 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
             // is not among a target's eight nearest --: worth one small readback to send them through the tiled kernels
             // instead of the list-mode ones.  A uniform mesh (no levels) leaves none or a handful: no readback.
             i64 list_len = -1;
-            if (lazy->index->fine) {
+            if (lazy->index->graded()) {
                 MM_HIP_CHECK(hipMemcpyAsync(ctx->h_counters + 1, slow_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 MM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 list_len = (i64) * reinterpret_cast<const int *>(ctx->h_counters + 1);

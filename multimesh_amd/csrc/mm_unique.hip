@@ -306,6 +306,48 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const double *__restrict__
 
 }  // namespace
 
+// The sort above for other callers (the kNN tree's Morton keys): stable LSD passes over the key bits [first_shift,
+// end_shift), 8 at a time, ping-pong between (ka, va) and (kb, vb); *in_a = the result lies in (ka, va).  scratch:
+// mm_radix_sort_scratch(n) bytes.
+size_t mm_radix_sort_scratch(i64 n)
+{
+    const i64 tiles = (n + kTile - 1) / kTile;
+    const i64 ncounts = (i64)kBins * tiles;
+    const i64 count_tiles = (ncounts + 1 + kScanTileItems - 1) / kScanTileItems;
+    return 2 * mm_round256((size_t)(ncounts + 1) * sizeof(int)) + mm_round256((size_t)count_tiles * sizeof(int));
+}
+
+int mm_radix_sort_pairs(mm_context *ctx, unsigned long long *ka, unsigned long long *kb, unsigned *va, unsigned *vb, i64 n,
+                        int first_shift, int end_shift, void *scratch, bool *in_a)
+{
+    *in_a = true;
+    if (n <= 0) return MM_OK;
+    const int tiles = (int)((n + kTile - 1) / kTile);
+    const i64 ncounts = (i64)kBins * tiles;
+    char *sp = (char *)scratch;
+    int *counts = (int *)sp;
+    sp += mm_round256((size_t)(ncounts + 1) * sizeof(int));
+    int *offsets = (int *)sp;
+    sp += mm_round256((size_t)(ncounts + 1) * sizeof(int));
+    int *count_sums = (int *)sp;
+    for (int shift = first_shift; shift < end_shift; shift += 8) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)tiles), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, tiles, counts);
+        const int src = mm_exclusive_scan_int(ctx, counts, ncounts, offsets, count_sums);
+        if (src != MM_OK) return src;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)tiles), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, tiles,
+                           offsets, kb, vb);
+        u64 *tk = ka;
+        ka = kb;
+        kb = tk;
+        unsigned *tv = va;
+        va = vb;
+        vb = tv;
+        *in_a = !*in_a;
+    }
+    MM_HIP_CHECK(hipGetLastError());
+    return MM_OK;
+}
+
 extern "C" int64_t mm_unique_points(mm_context *ctx, const double *points_d, int64_t npoints, int64_t dim,
                                     double *unique_d, int64_t *inverse_d)
 {

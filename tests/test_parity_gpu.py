@@ -745,6 +745,64 @@ def test_knn_two_densities_like_a_locally_refined_mesh(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("power,k", [(1.0, 8), (1.5, 20), (2.0, 8), (3.0, 20), (3.0, 3), (2.0, 40)])
+def test_knn_tree_on_graded_clouds(ctx, power, k, monkeypatch):
+    # the density-adaptive index (mm_knn_tree.inc.h: Morton-sorted sources, binary nodes, windows of cells found by
+    # searches on the keys, a second pass with wider margins, the single-target search) forced on: the same lists and
+    # distances as the k-d tree -- uniform cloud, graded ones, targets beyond the sources' box, k above the lane kernel's
+    # 20 (those queries take the level-0 grid)
+    monkeypatch.setenv("MM_KNN_TREE", "1")
+    rng = np.random.default_rng(29)
+    src = rng.uniform(size=(150_000, 3)) ** power
+    q = np.concatenate([rng.uniform(size=(40_000, 3)) ** power, rng.uniform(-0.2, 1.2, size=(5_000, 3)), src[:500]])
+    ref, dref = O.knn_ckdtree(src, q, k, workers=-1)
+    tree = ctx.knn_build(src)
+    for _ in range(2):
+        idx, dist = tree.query(q, k, want_dist=True)
+        assert np.array_equal(idx.numpy().reshape(len(q), k), ref.reshape(len(q), k))
+        np.testing.assert_allclose(dist.numpy().reshape(len(q), k), dref.reshape(len(q), k), rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_knn_tree_two_densities_and_a_cluster(ctx, monkeypatch):
+    # a refined region (27x the density), and a cluster of 130 k sources inside one finest cell's reach: nodes that stay
+    # too full however deep the tree goes -- their targets must come out of the single-target search
+    monkeypatch.setenv("MM_KNN_TREE", "1")
+    rng = np.random.default_rng(31)
+    src = np.concatenate([rng.uniform(size=(120_000, 3)), 0.35 + 0.2 * rng.uniform(size=(120_000, 3)),
+                          0.52 + 1e-6 * rng.normal(size=(131_000, 3))])
+    q = np.concatenate([rng.uniform(size=(30_000, 3)), 0.35 + 0.2 * rng.uniform(size=(30_000, 3)),
+                        0.52 + 1e-5 * rng.normal(size=(3_000, 3))])
+    for k in (8, 20):
+        assert np.array_equal(ctx.knn_build(src).query(q, k).numpy(), O.knn_ckdtree(src, q, k, workers=-1)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("power", [1.5, 2.2])
+def test_knn_tree_serves_the_fused_pipeline_on_a_graded_mesh(ctx, power, monkeypatch):
+    # the whole hex8 path over the tree: lazily evaluated lists of 8 in Morton order (the locate stage walks the targets in
+    # that order), the full lists of the targets that exhaust them through the tree again -- ids, weights, values and the
+    # failed count equal to the oracle's, as with the stack of density levels
+    monkeypatch.setenv("MM_KNN_TREE", "1")
+    pa, ca = synth.hex_mesh(61, seed=1, jitter=0.1)
+    pb, _ = synth.hex_mesh(75, seed=7, jitter=0.1)
+    pa, pb = pa ** power, pb ** power
+    fields = synth.vector_field(pa)[:2]
+    nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+    enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+    vals_o = O.gather(fields, enc_o, w_o)
+    for lazy in (True, False):
+        ctx.set_lazy_lists(lazy)
+        try:
+            vals, enc, w, nf = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20, want_operator=True)
+        finally:
+            ctx.set_lazy_lists(True)
+        assert nf == nf_o
+        assert np.array_equal(enc.numpy(), enc_o) and np.array_equal(w.numpy(), w_o)
+        assert np.array_equal(vals.numpy(), vals_o)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [4, 8])
 def test_knn_lane_kernel_next_to_a_cell_with_more_than_65535_sources(ctx, k):
     # a clustered cloud: one level-0 cell holds 131 k sources.  The lane kernel (level 0 of a multi-level grid for
