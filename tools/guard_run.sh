@@ -10,6 +10,10 @@ timeout -k 10 500 python tools/fuzz_knn.py $N 8101 > gpurun_out/guard/fuzz_knn_$
 [ $rc -eq 0 ] || exit $rc
 MM_KNN_KERNEL=lane timeout -k 10 500 python tools/fuzz_knn.py $N 8102 > gpurun_out/guard/fuzz_knn_lane_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_knn (lane forced) rc=$rc"; tail -1 gpurun_out/guard/fuzz_knn_lane_$TAG.log
 [ $rc -eq 0 ] || exit $rc
+MM_KNN_TREE=1 timeout -k 10 500 python tools/fuzz_knn.py $N 8107 > gpurun_out/guard/fuzz_knn_tree_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_knn (tree forced) rc=$rc"; tail -1 gpurun_out/guard/fuzz_knn_tree_$TAG.log
+[ $rc -eq 0 ] || exit $rc
+MM_KNN_TREE=1 FP_MODE=tol timeout -k 10 500 python tools/fuzz_pipeline.py $N 8108 > gpurun_out/guard/fuzz_pipe_tree_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_pipeline (tree forced, MM_FP_TOL) rc=$rc"; tail -1 gpurun_out/guard/fuzz_pipe_tree_$TAG.log
+[ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python tools/fuzz_pipeline.py $N 8103 > gpurun_out/guard/fuzz_pipe_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_pipeline rc=$rc"; tail -1 gpurun_out/guard/fuzz_pipe_$TAG.log
 [ $rc -eq 0 ] || exit $rc
 FP_MODE=tol timeout -k 10 500 python tools/fuzz_pipeline.py $N 8106 > gpurun_out/guard/fuzz_pipe_tol_$TAG.log 2>&1; rc=$?; echo "guarded fuzz_pipeline (MM_FP_TOL) rc=$rc"; tail -1 gpurun_out/guard/fuzz_pipe_tol_$TAG.log
