@@ -674,8 +674,9 @@ static TreeParams tree_params_of(const mm_knn_tree *tr)
 // MM_KNN_TREE: 0 = never (the stack of density levels only), 1 = for every 3-D cloud of at least kLevelMinSources sources
 // (tests, experiments), unset = where the stack ends: when the grid statistic of level 0 asks for the DEEPEST level the
 // stack can lay out (sources in cells of 256 x the design density and more -- the stack stops there, the tree does not).
-// Measured, round 4 (ms per pass; stack / tree): graded 10M hex8 mesh u^1.5 12.3 / 12.1, u^2.2 47.0 / 38.6; random 4M clouds,
-// k = 20, u^1.5 5.9 / 16.7, u^2 10.0 / 18.1, u^3 25.5 / 19.8; a 27 x refined region, k = 8: 3.4 / 5.4.  Read per call.
+// Measured, round 4 (ms per pass; stack / tree; profiles/r04_graded_mesh_pipeline.json, r04_knn_graded_clouds.json): graded 10M
+// hex8 mesh u^1.5 12.8 / 12.1, u^2.2 47.5 / 38.7, uniform 3.46 / 7.5; random 4M clouds, k = 20: uniform 2.4 / 16.3, u^1.5 5.9 / 16.7,
+// u^2 10.2 / 18.1, u^3 26.3 / 19.7; a 27 x refined region, k = 8: 3.4 / 5.1.  Read per call.
 static int tree_mode()
 {
     const char *env = getenv("MM_KNN_TREE");
