@@ -589,7 +589,10 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         const int mode = tree_mode();
         bool cube = ndim == 3 && nsrc >= kLevelMinSources;
         for (int a = 0; a < 3 && cube; ++a) cube = box[3 + a] - box[a] > 0.0 && isfinite(box[3 + a] - box[a]);
-        if (cube && (mode == 1 || (mode == -1 && (extra & (1 << (kMaxLevels - 2))) != 0 && max_levels > 1))) {
+        // (box_partial_d: the fused pipeline's build -- the sources are a mesh's centroids, the queries lists of 8 and then of
+        // 20 for a few: there the tree is ahead as soon as the cloud asks for levels at all)
+        const bool deepest = (extra & (1 << (kMaxLevels - 2))) != 0, mesh_graded = box_partial_d != nullptr && extra != 0;
+        if (cube && (mode == 1 || (mode == -1 && (deepest || mesh_graded) && max_levels > 1))) {
             rc = tree_build(ctx, head, src_d, nsrc, box, use_context_buffers);
             if (rc != MM_OK) {
                 free_index(head);
@@ -672,11 +675,12 @@ static TreeParams tree_params_of(const mm_knn_tree *tr)
 }
 
 // MM_KNN_TREE: 0 = never (the stack of density levels only), 1 = for every 3-D cloud of at least kLevelMinSources sources
-// (tests, experiments), unset = where the stack ends: when the grid statistic of level 0 asks for the DEEPEST level the
-// stack can lay out (sources in cells of 256 x the design density and more -- the stack stops there, the tree does not).
+// (tests, experiments), unset = where it is ahead: (a) where the stack ends -- the grid statistic of level 0 asks for the
+// DEEPEST level the stack can lay out (sources in cells of 256 x the design density and more) --, (b) in the fused hex8
+// pipeline whenever the centroids ask for density levels at all.
 // Measured, round 4 (ms per pass; stack / tree; profiles/r04_graded_mesh_pipeline.json, r04_knn_graded_clouds.json): graded 10M
-// hex8 mesh u^1.5 12.8 / 12.1, u^2.2 47.5 / 38.7, uniform 3.46 / 7.5; random 4M clouds, k = 20: uniform 2.4 / 16.3, u^1.5 5.9 / 16.7,
-// u^2 10.2 / 18.1, u^3 26.3 / 19.7; a 27 x refined region, k = 8: 3.4 / 5.1.  Read per call.
+// hex8 mesh u^1.5 12.8 / 11.2, u^2.2 47.4 / 37.3, uniform 3.43 / 7.5; random 4M clouds, k = 20: uniform 2.4 / 16.6, u^1.5 5.9 / 15.4,
+// u^2 10.0 / 16.5, u^3 25.7 / 20.0; a 27 x refined region, k = 8: 3.3 / 5.0.  Read per call.
 static int tree_mode()
 {
     const char *env = getenv("MM_KNN_TREE");

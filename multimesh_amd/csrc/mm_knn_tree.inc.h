@@ -342,13 +342,12 @@ __global__ __launch_bounds__(kBlock) void tree_items_kernel(const u64 *__restric
     items[rank[t]] = it;
 }
 
-// The tree's search for single targets (what the windows of the lane kernel could not certify, short lists): one lane per
-// target, the generic kernel's rule on the tree's cells -- the 3 x 3 x 3 block of octree cells around the target, its own
-// cell first and every other one only if it can hold something nearer than the k-th so far, accepted when the k-th
-// distance is below the block's faces; else the block of cells of twice the edge.  It starts at the level where the
-// target's own cell holds k sources (a target in a small empty node -- anisotropic lattices, hulls -- would otherwise climb
-// level by level, 54 searches each).  Measured against it on the graded 10M mesh (hand-overs of a k = 8 query, ns per
-// target): shells of same-size cells 4.7, a ball around the k nearest in Morton order cut into cells 24, this one 2.3.
+// The tree's search for single targets (what the windows of the lane kernel could not certify, long lists of them): one
+// lane per target, the generic kernel's rule on the tree's cells -- the 3 x 3 x 3 block of octree cells around the target, its
+// own cell first and every other one only if it can hold something nearer than the k-th so far, accepted when the k-th
+// distance is below the block's faces; else the block of cells of twice the edge.  Measured on the way (graded 10M mesh,
+// hand-overs of a k = 8 query, ns per target): blocks of leaf-sized cells found by searches 2.3 - 6.5 (u^2.2: 4.5, k = 20: 14),
+// shells of same-size cells 4.7, a ball around the k nearest in Morton order cut into cells 24.
 template <int K, typename IDX>
 __global__ __launch_bounds__(kBlock) void tree_ring_kernel(TreeParams tp, const u64 *__restrict__ keys,
                                                            const int *__restrict__ coarse,
@@ -369,8 +368,16 @@ __global__ __launch_bounds__(kBlock) void tree_ring_kernel(TreeParams tp, const 
         const double pz = ndim > 2 ? pts[i * pstride + 2] : 0.0;
         const unsigned qx = tree_quant(px, tp.lox, tp.scale), qy = tree_quant(py, tp.loy, tp.scale), qz = tree_quant(pz, tp.loz, tp.scale);
         const u64 key = tree_morton(qx, qy, qz);
-        int lvl = tree_leaf_bits(keys, slevel, nsrc, key, tree_lower_bound(keys, coarse, nsrc, key)) / 3;
-        while (lvl > 0 && tree_node_count(keys, coarse, nsrc, key, 3 * lvl) < kout) --lvl;
+        // Blocks of cells of level <= kTreeL0 only: their runs come straight out of the search table (no search on the keys),
+        // and inside a cell the pruned descent below goes wherever the k-th ball reaches -- in a dense place the target's own
+        // cell is entered nearest-part-first and the 26 around it are skipped by their boxes, in an anisotropic one the
+        // descent follows the ball instead of climbing level after level.  Start where the own cell holds k sources.
+        int lvl = kTreeL0;
+        while (lvl > 0) {
+            const int c = (int)(key >> (3 * (kTreeQ - lvl))), up = 3 * (kTreeL0 - lvl);
+            if (coarse[(c + 1) << up] - coarse[c << up] >= kout) break;
+            --lvl;
+        }
         BestList<K> best;
         int st_a[kTreeBits + 2], st_b[kTreeBits + 2], st_p[kTreeBits + 2];
         u64 st_k[kTreeBits + 2];
@@ -400,9 +407,9 @@ __global__ __launch_bounds__(kBlock) void tree_ring_kernel(TreeParams tp, const 
                                 const double ddz = fmax(fmax(zl - pz, pz - (zl + cl)) - slack, 0.0);
                                 if (ddx * ddx + ddy * ddy + ddz * ddz > kth_now) continue;
                             }
-                            const u64 k0 = tree_morton((unsigned)gx, (unsigned)gy, (unsigned)gz) << (3 * sh);
-                            const int s0 = tree_lower_bound(keys, coarse, nsrc, k0);
-                            const int s1 = tree_lower_bound(keys, coarse, nsrc, k0 + (1ull << (3 * sh)));
+                            const u64 cm = tree_morton((unsigned)gx, (unsigned)gy, (unsigned)gz);
+                            const u64 k0 = cm << (3 * sh);
+                            const int s0 = coarse[(int)cm << (3 * (kTreeL0 - l))], s1 = coarse[((int)cm + 1) << (3 * (kTreeL0 - l))];
                             // The cell's sources, nearest parts first: a run of more than kTreeScanMax sources is cut in two
                             // at the next key bit (one search inside the run) and a half is only entered if its box can hold
                             // something nearer than the k-th so far -- beside a much denser region a cell of the target's own
