@@ -807,7 +807,7 @@ static void tree_ring(mm_context *ctx, const mm_knn_index *ix, const double *pts
 }
 
 // lists shorter than this go straight to the ring search (sparse targets fill no 64-lane rounds)
-constexpr i64 kTreeRingListMax = 8192;
+constexpr i64 kTreeRingListMax = 65536;
 
 // A query through the tree: the targets (all of them, or those of a device-side list whose length list_len the caller has
 // read back) in Morton order, one work item per run of at most 256 targets of one node, the lane kernel's TREE

@@ -271,16 +271,52 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             const int ncl = 1 << tree_lc;
             const int sh = 3 * shq;
             const int wcells = tree_nax * tree_nay * tree_naz;
+            // (all of a lane's searches advance together, one step per trip: their loads are in flight at once -- done one
+            // after the other, eight searches of ~6 dependent loads each were half of an item's time)
+            u64 kq[2 * NB];
+            int blo[2 * NB], bhi[2 * NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int q = lane + 64 * b;
                 const int iz = q / (tree_nax * tree_nay), r2 = q - iz * tree_nax * tree_nay, iy = r2 / tree_nax, ix = r2 - iy * tree_nax;
                 const int gx = tree_bx + ix, gy = tree_by + iy, gz = tree_bz + iz;
-                if (q < wcells && (unsigned)gx < (unsigned)ncl && (unsigned)gy < (unsigned)ncl && (unsigned)gz < (unsigned)ncl) {
-                    const u64 k0 = tree_morton((unsigned)gx, (unsigned)gy, (unsigned)gz) << sh;
-                    s0[b] = tree_lower_bound(ta.keys, ta.coarse, (int)nsrc, k0);
-                    cnt[b] = min(tree_lower_bound(ta.keys, ta.coarse, (int)nsrc, k0 + (1ull << sh)) - s0[b], kLaneTileCap + 1);
+                const bool in = q < wcells && (unsigned)gx < (unsigned)ncl && (unsigned)gy < (unsigned)ncl && (unsigned)gz < (unsigned)ncl;
+                const u64 k0 = tree_morton((unsigned)(in ? gx : 0), (unsigned)(in ? gy : 0), (unsigned)(in ? gz : 0)) << sh;
+                kq[2 * b] = k0;
+                kq[2 * b + 1] = k0 + (1ull << sh);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u64 key = kq[2 * b + e];
+                    const bool past = (key >> kTreeBits) != 0;
+                    const int c = past ? 0 : (int)(key >> kTreeShift0);
+                    const int a0 = ta.coarse[c], a1 = ta.coarse[c + 1];
+                    blo[2 * b + e] = !in ? 0 : (past ? (int)nsrc : a0);
+                    bhi[2 * b + e] = !in ? 0 : (past ? (int)nsrc : a1);
                 }
+            }
+            for (;;) {
+                u64 kv[2 * NB];
+                int mid[2 * NB];
+#pragma unroll
+                for (int j = 0; j < 2 * NB; ++j) {
+                    mid[j] = (blo[j] + bhi[j]) >> 1;
+                    kv[j] = ta.keys[min(mid[j], (int)nsrc - 1)];
+                }
+                bool more = false;
+#pragma unroll
+                for (int j = 0; j < 2 * NB; ++j) {
+                    if (blo[j] < bhi[j]) {
+                        if (kv[j] < kq[j]) blo[j] = mid[j] + 1;
+                        else bhi[j] = mid[j];
+                    }
+                    more = more || blo[j] < bhi[j];
+                }
+                if (!__any(more)) break;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                s0[b] = blo[2 * b];
+                cnt[b] = min(blo[2 * b + 1] - blo[2 * b], kLaneTileCap + 1);
             }
             // (the tile's frame: the corner of the cell behind the window's first one, i.e. the node's own corner)
             ox = ta.tp.lox + (double)(tree_bx + 1) * tree_c;
