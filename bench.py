@@ -121,7 +121,7 @@ def gll_bytes(n_targets, n_elem, P, dim, k, ncomp):
 #: stages that are ONE kernel launch each (candidates for the "dominant kernel" roofline), by the name
 #: rocprofv3 --kernel-trace prints for them (profiles/*_kernel_stats.csv)
 SINGLE_KERNEL_STAGES = ("centroid", "knn_cell", "locate_pass0", "gather")
-KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_lane_kernel<8, int>",
+KERNEL_OF_STAGE = {"centroid": "centroid_bbox_kernel", "knn_cell": "knn_lane_kernel<8, int, false>",
                    "locate_pass0": "locate_pass_kernel<true, int, true, int, true>", "gather": "gather8_kernel<true>"}
 LOCATE_KERNEL = {"tol": "locate_pass_kernel<true, int, true, int, true>", "exact": "locate_pass_kernel<true, int, true, int, false>"}
 #: what the counters say limits each of them: the two big kernels sit on the vector-issue
