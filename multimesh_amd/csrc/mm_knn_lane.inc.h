@@ -251,20 +251,20 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             const TreeItem it = ta.items[q0 + m8];
             t0 = it.t0;
             tn = ta.items[q0 + m8 + 1].t0 - t0;
-            // the node: P leading key bits -- the octree cell of level P / 3, halved along z (P % 3 >= 1) and y (P % 3 == 2);
+            // the node: P leading key bits -- the octree cell of level P / 3, halved along x (P % 3 >= 1) and y (P % 3 == 2);
             // its window: one cell of level P / 3 + d around it (mm_knn_tree.inc.h)
             const int P = (int)((it.node >> kTreeLevelShift) & 0x3f), deeper = (int)(it.node >> 62);
             const u64 k0n = it.node & ((1ull << kTreeLevelShift) - 1ull);
             tree_lc = P / 3 + deeper;
             const int shq = kTreeQ - tree_lc;
             // (the node's first key is its corner: the low bits are zero)
-            tree_bx = (int)(tree_compact3(k0n) >> shq) - 1;
-            tree_by = (int)(tree_compact3(k0n >> 1) >> shq) - 1;
-            tree_bz = (int)(tree_compact3(k0n >> 2) >> shq) - 1;
+            tree_bx = (int)(tree_key_x(k0n) >> shq) - 1;
+            tree_by = (int)(tree_key_y(k0n) >> shq) - 1;
+            tree_bz = (int)(tree_key_z(k0n) >> shq) - 1;
             const int jj = P - 3 * (P / 3), aa = 1 << deeper;
-            tree_nax = aa + 2;
+            tree_nax = (jj >= 1 ? aa >> 1 : aa) + 2;
             tree_nay = (jj >= 2 ? aa >> 1 : aa) + 2;
-            tree_naz = (jj >= 1 ? aa >> 1 : aa) + 2;
+            tree_naz = aa + 2;
             tree_c = ta.tp.size / (double)(1 << tree_lc);
             nlayers = tree_naz;
             // ---- extents of the window's cells, up to four per lane: two searches on the sorted keys each
