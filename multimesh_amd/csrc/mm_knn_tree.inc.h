@@ -44,7 +44,7 @@ constexpr int kTreeNmax = 64;                         // sources per leaf
 //   P % 3 = 2        :      2 x 2 x 4,              4 x 4 x 6 (6 x)                                    1 x 1 x 2 -> 3 x 3 x 4 (18 x)
 //   P % 3 = 0, d = 0 : the node is one cell, window 3 x 3 x 3 (27 x)
 // The margin certifies a list of k when a cell holds enough sources (its edge against the local spacing: ~2 for k <= 8,
-// ~5 for k = 20), and the window must fit the tile.  tree_target_node_kernel takes, among the leaf around a target and its
+// ~8 for k = 20), and the window must fit the tile.  tree_target_node_kernel takes, among the leaf around a target and its
 // three nearest ancestors, the node with the most sources that has such a window (most targets per work item).
 constexpr int kTreeLevelShift = 56;                   // a node = its first key | P << 56 | d << 62
 constexpr int kTreeTileMax = 700;                     // expected sources of a window (the tile holds kLaneTileCap = 768)
