@@ -653,7 +653,8 @@ __global__ __launch_bounds__(kWave, 3) void knn_lane_kernel(GridParams g, i64 ns
             {
                 // every source outside the list lies at an exact distance >= lb (header comment)
                 const double E = 3.0 * kU * (fabs(px - ox) + fabs(py - oy) + fabs(pz - oz) +
-                                             (TREE ? 12.0 * tree_c : 2.0 * (g.hx + g.hy) + (double)(Z + 1) * g.hz));
+                                             (TREE ? (double)(tree_nax + tree_nay + tree_naz) * tree_c
+                                                   : 2.0 * (g.hx + g.hy) + (double)(Z + 1) * g.hz));
                 const float B = d[L - 1];
                 if (B < kLaneFarKey) {
                     // (v_sqrt_f32 is within 1 ulp: 2^-21 more off the factor covers it)
