@@ -526,7 +526,7 @@ static int tree_build(mm_context *ctx, mm_knn_index *ix, const double *src_d, i6
 
 // Build without touching the stage timers (used by the fused pipeline too).
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers, const double *box_partial_d, int box_nblocks)
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks, bool hex8_centroids)
 {
     *out = nullptr;
     // bounding box: per-workgroup boxes -- left by the fused pipeline's centroid kernel (box_partial_d), or by
@@ -589,9 +589,10 @@ int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, 
         const int mode = tree_mode();
         bool cube = ndim == 3 && nsrc >= kLevelMinSources;
         for (int a = 0; a < 3 && cube; ++a) cube = box[3 + a] - box[a] > 0.0 && isfinite(box[3 + a] - box[a]);
-        // (box_partial_d: the fused pipeline's build -- the sources are a mesh's centroids, the queries lists of 8 and then of
-        // 20 for a few: there the tree is ahead as soon as the cloud asks for levels at all)
-        const bool deepest = (extra & (1 << (kMaxLevels - 2))) != 0, mesh_graded = box_partial_d != nullptr && extra != 0;
+        // (box_partial_d / hex8_centroids: the fused hex8 pipeline's build, per call or for a resident source -- the sources
+        // are a mesh's centroids, the queries lists of 8 and then of 20 for a few: there the tree is ahead as soon as the
+        // cloud asks for levels at all)
+        const bool deepest = (extra & (1 << (kMaxLevels - 2))) != 0, mesh_graded = (box_partial_d != nullptr || hex8_centroids) && extra != 0;
         if (cube && (mode == 1 || (mode == -1 && (deepest || mesh_graded) && max_levels > 1))) {
             rc = tree_build(ctx, head, src_d, nsrc, box, use_context_buffers);
             if (rc != MM_OK) {
@@ -1267,7 +1268,7 @@ extern "C" int mm_knn_build(mm_context *ctx, const double *src_d, int64_t nsrc, 
     MM_HIP_CHECK(hipSetDevice(ctx->device));
     mm_stage_reset(ctx);
     mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out, false, nullptr, 0);
+    int rc = mm_knn_build_impl(ctx, src_d, nsrc, ndim, out, false, nullptr, 0, false);
     mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     return rc;
 }

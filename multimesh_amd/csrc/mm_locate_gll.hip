@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void gll_order_kernel(i64 npoints, const int2 
 
 int mm_exclusive_scan_int(mm_context *ctx, const int *counts, i64 n, int *start, int *tile_sums);
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers, const double *box_partial_d, int box_nblocks);
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks, bool hex8_centroids = false);
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
                       double *dist_d, bool idx_is_int32);
 

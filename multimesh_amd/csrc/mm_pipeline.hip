@@ -8,7 +8,7 @@
 #include "mm_common.h"
 
 int mm_knn_build_impl(mm_context *ctx, const double *src_d, i64 nsrc, i64 ndim, mm_knn_index **out,
-                      bool use_context_buffers, const double *box_partial_d, int box_nblocks);
+                      bool use_context_buffers, const double *box_partial_d, int box_nblocks, bool hex8_centroids = false);
 int mm_knn_query_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, void *idx_d,
                       double *dist_d, bool idx_is_int32);
 int mm_knn_query_sorted_impl(mm_context *ctx, const mm_knn_index *ix, const double *pts_d, i64 npts, i64 k, int *idx_d,
@@ -285,7 +285,7 @@ extern "C" int mm_source_create(mm_context *ctx, const double *nodes_d, int64_t 
     }
     if (rc == MM_OK) {
         mm_stage_begin(ctx, MM_STAGE_KNN_BUILD);
-        rc = mm_knn_build_impl(ctx, s->centroids, nelem, 3, &s->index, /*use_context_buffers=*/false, nullptr, 0);
+        rc = mm_knn_build_impl(ctx, s->centroids, nelem, 3, &s->index, /*use_context_buffers=*/false, nullptr, 0, /*hex8_centroids=*/true);
         mm_stage_end(ctx, MM_STAGE_KNN_BUILD);
     }
     if (rc == MM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {

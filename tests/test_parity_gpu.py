@@ -984,6 +984,27 @@ def test_resident_source_gives_the_fused_path_bit_for_bit(ctx, golden):
         src.free()
 
 
+def test_resident_source_on_a_graded_mesh(ctx):
+    # a graded source mesh kept resident: its index is the density-adaptive tree (as in the per-call build); the tree's
+    # arrays belong to the handle, queries of several target sets interleave with fused calls that build their own
+    pa, ca = synth.hex_mesh(61, seed=1, jitter=0.1)
+    pa = pa ** 1.8
+    fields = synth.vector_field(pa)[:2]
+    src = ctx.source(pa, ca)
+    try:
+        for seed, n in ((7, 75), (8, 50), (9, 64)):
+            pb, _ = synth.hex_mesh(n, seed=seed, jitter=0.1)
+            pb = pb ** 1.8
+            a, nfa = src.interpolate(pb, fields, nelem_to_search=20)
+            b, nfb = ctx.interpolate_hex8(pa, ca, pb, fields, nelem_to_search=20)
+            assert nfa == nfb and np.array_equal(a.numpy(), b.numpy())
+            nn, _ = O.knn_ckdtree(O.centroid(ca, pa), pb, 20, workers=-1)
+            enc_o, w_o, nf_o = O.locate_hex8(nn, synth.reorder_hex8(ca), pa, pb)
+            assert nf_o == nfa and np.array_equal(a.numpy(), O.gather(fields, enc_o, w_o))
+    finally:
+        src.free()
+
+
 # ------------------------------------------------------------------------------- targets that fill part of the grid
 def test_knn_targets_in_a_slab_choose_their_kernel_by_occupied_strips(ctx):
     # One rank's share of a sharded target set is a slab: the full problem's density inside, nothing outside.  The average
