@@ -23,6 +23,12 @@ PATTERNS = {"knn_strip_kernel": "knn_strip_kernel", "knn_lane_kernel": "knn_lane
 
 
 def short(name):
+    # the kNN tree's kernels (graded clouds): the lane kernel's TREE instantiations apart from the uniform ones
+    if "knn_lane_kernel<" in name and name.split("knn_lane_kernel<")[1].split(">(")[0].endswith(", true"):
+        return "knn_lane_kernel_tree_k" + name.split("knn_lane_kernel<")[1].split(",")[0]
+    for pat in ("tree_ring_kernel", "tree_target_node_kernel", "radix_scatter_kernel", "knn_list_wave_kernel"):
+        if pat in name:
+            return pat
     if "locate_pass_kernel" in name:
         # two instances since round 4: <..., true> = MM_FP_TOL's (the bench default), <..., false> = the reference's
         # arithmetic (bench.py runs a few steps of the other mode beside the timed ones)
