@@ -778,6 +778,31 @@ def test_knn_tree_two_densities_and_a_cluster(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_knn_tree_edge_cases(ctx, monkeypatch):
+    # the smallest cloud the tree takes (4096 sources: a 2 M-entry search table over a handful of leaves), every target
+    # outside the sources' box (all keys clamped into boundary cells), k = 1 and k = 20, sources on a plane of the cube
+    # (two axes of full extent, one of 1e-9: nodes that are all slabs) and sixty-fold duplicates of one point
+    monkeypatch.setenv("MM_KNN_TREE", "1")
+    rng = np.random.default_rng(37)
+    src = rng.uniform(size=(4096, 3))
+    far = np.concatenate([rng.uniform(1.5, 3.0, size=(3000, 3)), rng.uniform(-2.0, -0.5, size=(3000, 3))])
+    for k in (1, 20):
+        assert np.array_equal(ctx.knn_build(src).query(far, k).numpy().reshape(len(far), k),
+                              O.knn_ckdtree(src, far, k, workers=-1)[0].reshape(len(far), k))
+    flat = rng.uniform(size=(60_000, 3)) * np.array([1.0, 1.0, 1e-9])
+    q = rng.uniform(size=(20_000, 3)) * np.array([1.0, 1.0, 1e-9])
+    assert np.array_equal(ctx.knn_build(flat).query(q, 8).numpy(), O.knn_ckdtree(flat, q, 8, workers=-1)[0])
+    dup = np.concatenate([rng.uniform(size=(20_000, 3)), np.repeat(rng.uniform(size=(500, 3)), 60, axis=0)])
+    q = rng.uniform(size=(10_000, 3))
+    idx, dist = ctx.knn_build(dup).query(q, 8, want_dist=True)
+    ref_i, ref_d = O.knn_ckdtree(dup, q, 8, workers=-1)
+    np.testing.assert_allclose(dist.numpy().reshape(len(q), 8), ref_d.reshape(len(q), 8), rtol=1e-12, atol=0)
+    far_from_dups = (ref_d.reshape(len(q), 8)[:, -1] < np.inf)   # ids: equal where no tie among duplicates decides
+    same = (idx.numpy().reshape(len(q), 8) == ref_i.reshape(len(q), 8)).all(axis=1)
+    assert same.mean() > 0.5 and far_from_dups.all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("power", [1.5, 2.2])
 def test_knn_tree_serves_the_fused_pipeline_on_a_graded_mesh(ctx, power, monkeypatch):
     # the whole hex8 path over the tree: lazily evaluated lists of 8 in Morton order (the locate stage walks the targets in
