@@ -915,13 +915,18 @@ static int tree_query(mm_context *ctx, const mm_knn_index *ix, const double *pts
         ta.nitems = nitems_d;
         const unsigned wgs = (unsigned)(8 * (nitems / 8 + 1));
         const GridParams g = params_of(ix);
-        const int T = kLaneThin;
+        // thin layers per cell layer and half-width of a target's first window (a tree window has at most 6 cell layers:
+        // 6 T <= kLaneThinMax).  MM_TREE_T / MM_TREE_W: tuning experiments only.
+        static const int env_t = getenv("MM_TREE_T") ? atoi(getenv("MM_TREE_T")) : 0;
+        static const int env_w = getenv("MM_TREE_W") ? atoi(getenv("MM_TREE_W")) : 0;
+        const int T = env_t >= 1 && 6 * env_t <= kLaneThinMax ? env_t : kLaneThin;
+        const int W8 = env_w >= 1 && env_w <= T ? env_w : (T == kLaneThin ? kLaneWin : T);
         if (!list) mm_stage_begin(ctx, MM_STAGE_KNN_CELL);
 #define MM_TREE_LANE(KK)                                                                                                          \
     hipLaunchKernelGGL((knn_lane_kernel<KK, IDX, true>), dim3(wgs), dim3(kWave), 0, ctx->stream, g, ix->nsrc, (const int *)nullptr, \
                        (const double *)tr->xyz, ix->ndim, kout, (const int *)nullptr, (const double *)tsorted, idx_d, dist_d,      \
                        fb_list, fb_count, (const int2 *)nullptr, 0, 1, kWave * kLaneRounds, sorted_rows ? 1 : 0, down_list,        \
-                       down_list ? fb_count + 3 : (int *)nullptr, T, KK <= 8 ? kLaneWin : T, ta)
+                       down_list ? fb_count + 3 : (int *)nullptr, T, KK <= 8 ? W8 : T, ta)
         if (kout <= 1) MM_TREE_LANE(1);
         else if (kout <= 2) MM_TREE_LANE(2);
         else if (kout <= 4) MM_TREE_LANE(4);
