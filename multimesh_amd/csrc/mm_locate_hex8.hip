@@ -195,11 +195,12 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
                                                           unsigned long long *__restrict__ nfailed,
                                                           const int *__restrict__ list,
                                                           const int *__restrict__ list_count, int zero_failed,
-                                                          const int *__restrict__ abort6 = nullptr)
+                                                          const int *__restrict__ abort6 = nullptr, int list_min = -1)
 {
     if (mm_aborted(abort6)) return;   // (a guessed grid that is not this call's: the host runs the call again)
     // list != null: only the queued targets (left over by the fast passes), grid-stride
     const i64 total = list ? (i64)*list_count : npoints;
+    if (list && total <= (i64)list_min) return;   // (shorter lists: locate_hex8_group_kernel, one candidate per lane)
     const i64 stride = (i64)gridDim.x * blockDim.x;
     const i64 q0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     // every lane of a wave runs the same number of trips so that the ballot below is wave-wide
@@ -257,6 +258,95 @@ __global__ __launch_bounds__(256) void locate_hex8_kernel(i64 k, i64 npoints,
     }
 }
 
+// The same verdicts with ONE CANDIDATE PER LANE: G lanes share a target, lane j solves candidate j (every solve starts
+// from xi = 0 and is deterministic, so its result does not depend on who runs it), then the group takes what the loop
+// above would have taken -- the first candidate, in list order, accepted below 1.025; else the first one of smallest
+// max |xi| among those that converged inside the hull, if below 1.5 (the loop solves that one again: same iterates, same
+// weights).  The targets that reach this kernel have found no acceptance in the passes: the loop walks all k candidates
+// for each of them, up to the reference's 50 trips apiece, on one lane -- on a graded 10M mesh the slowest lanes made the
+// launch last 0.5 - 1 ms for a few tens of thousands of targets (u^2.2: 2.9 ms); here a target's critical path is one solve.
+// Lists longer than list_max keep the loop (as many lanes as targets fill the chip there, at full lane use).
+template <bool EXODUS, typename IDX, int G>
+__global__ __launch_bounds__(256) void locate_hex8_group_kernel(i64 k, i64 npoints, const IDX *__restrict__ nn,
+                                                                const i64 *__restrict__ conn, i64 nelem, Emit em,
+                                                                const double *__restrict__ nodes,
+                                                                const double *__restrict__ pts,
+                                                                unsigned long long *__restrict__ nfailed,
+                                                                const int *__restrict__ list,
+                                                                const int *__restrict__ list_count, int zero_failed,
+                                                                int list_max, const int *__restrict__ abort6 = nullptr)
+{
+    static_assert(G == 32 || G == 64, "a group is a wave or half of one");
+    if (mm_aborted(abort6)) return;
+    const i64 total = (i64)*list_count;
+    if (total > (i64)list_max) return;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & (G - 1);
+    const i64 per_block = 256 / G;
+    const i64 stride = (i64)gridDim.x * per_block;
+    const i64 trips = (total + stride - 1) / stride;
+    for (i64 trip = 0; trip < trips; ++trip) {
+        const i64 q = (i64)blockIdx.x * per_block + threadIdx.x / G + trip * stride;
+        const i64 i = q < total ? (i64)list[q] : npoints;
+        const bool live = i < npoints && k > 0;
+        bool ok = false;
+        double worst = INFINITY;
+        Corners c;
+        double xi[3] = {0.0, 0.0, 0.0};
+        if (live && sub < k) {
+            const i64 elem = (i64)nn[i * k + sub];
+            if (!(nelem > 0 && (unsigned long long)elem >= (unsigned long long)nelem)) {
+                const double px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+                load_corners<EXODUS>(conn, nodes, elem, c);
+                if (newton_hex8(px, py, pz, c.x, c.y, c.z, xi) && in_hull(xi)) {
+                    ok = true;
+                    worst = max_abs3(xi);
+                }
+            }
+        }
+        // the first candidate, in list order, accepted below 1.025
+        const unsigned long long acc = __ballot(ok && worst < (1 + 0.025));
+        const unsigned long long mine = G == 64 ? acc : (acc >> (lane & 32)) & 0xffffffffull;
+        bool failed = false;
+        if (live) {
+            double wt[8];
+            if (mine) {
+                if (sub == __ffsll((long long)mine) - 1) {
+                    weights_hex8(xi, wt);
+                    emit_row(em, i, c.id, wt);
+                }
+            } else {
+                // the first candidate of smallest max |xi| (the loop: `worst < smallest`, strictly)
+                double bw = worst;
+                int bj = sub;
+#pragma unroll
+                for (int off = G / 2; off >= 1; off >>= 1) {
+                    const double ow = __shfl_xor(bw, off);
+                    const int oj = __shfl_xor(bj, off);
+                    if (ow < bw || (ow == bw && oj < bj)) {
+                        bw = ow;
+                        bj = oj;
+                    }
+                }
+                if (bw < 1.5) {
+                    if (sub == bj) {
+                        weights_hex8(xi, wt);
+                        emit_row(em, i, c.id, wt);
+                    }
+                } else if (sub == 0) {
+                    failed = true;
+                    if (zero_failed) {
+                        const i64 zid[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        const double zw[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                        emit_row(em, i, zid, zw);
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(failed);
+        if (lane == 0 && mask) atomicAdd(nfailed, (unsigned long long)__popcll(mask));
+    }
+}
+
 #ifndef MM_PASS_ITERS   // tuning builds only
 #define MM_PASS_ITERS 6
 #endif
@@ -291,6 +381,7 @@ constexpr int kRefIters = 50;               // the reference's own cap (trilinea
 // same verdict) in a round where slow solves only keep each other company.  "Not converged" under
 // the reference's cap rejects the candidate, as in the reference.
 constexpr int kPassBlock = 256;
+constexpr int kGroupListMax = 1 << 16;   // reference-order lists up to this long: one candidate per lane (u^2.2 graded mesh, ~0.5 M on the list: loop 2.9 ms, groups 3.8; u^1.5, 30 k: 1.0 -> 0.1)
 #ifndef MM_PASS_WAVES   // tuning builds only: minimum waves per SIMD the register allocator must leave room for
 #define MM_PASS_WAVES 2
 #endif
@@ -923,14 +1014,36 @@ static int launch_locate_typed(mm_context *ctx, i64 k, i64 npoints, const IDX *n
         i64 sgrid = full_grid >> 3;
         if (sgrid < 256) sgrid = full_grid < 256 ? full_grid : 256;
         dim3 g((unsigned)sgrid), b(block);
+        // Two launches, one of which returns at once: lists up to kGroupListMax take one candidate per lane (a target's
+        // critical path is ONE solve), longer ones the loop (see locate_hex8_group_kernel).  MM_LOCATE_GROUP=0: the loop only.
+        static const int group_max = getenv("MM_LOCATE_GROUP") && atoi(getenv("MM_LOCATE_GROUP")) == 0 ? -1 : kGroupListMax;
+        if (group_max >= 0 && k_slow <= 64) {
+            i64 ggrid = (npoints * (k_slow <= 32 ? 32 : 64) + 255) / 256;
+            if (ggrid > 8192) ggrid = 8192;
+            if (ggrid < 1) ggrid = 1;
+            dim3 gg((unsigned)ggrid);
+#define MM_GROUP(EX, GG)                                                                                                   \
+    hipLaunchKernelGGL((locate_hex8_group_kernel<EX, IDX, GG>), gg, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn, nelem, em, \
+                       nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed, group_max,                \
+                       (const int *)ctx->abort_flags)
+            if (conn_is_exodus) {
+                if (k_slow <= 32) MM_GROUP(true, 32);
+                else MM_GROUP(true, 64);
+            } else {
+                if (k_slow <= 32) MM_GROUP(false, 32);
+                else MM_GROUP(false, 64);
+            }
+#undef MM_GROUP
+        }
+        const int loop_min = group_max >= 0 && k_slow <= 64 ? group_max : -1;
         if (conn_is_exodus)
             hipLaunchKernelGGL((locate_hex8_kernel<true, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
                                nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed,
-                               (const int *)ctx->abort_flags);
+                               (const int *)ctx->abort_flags, loop_min);
         else
             hipLaunchKernelGGL((locate_hex8_kernel<false, IDX>), g, b, 0, ctx->stream, k_slow, npoints, nn_slow, conn,
                                nelem, em, nodes, pts, (unsigned long long *)d_nfailed, slow, slow_count, zero_failed,
-                               (const int *)ctx->abort_flags);
+                               (const int *)ctx->abort_flags, loop_min);
     }
     MM_HIP_CHECK(hipGetLastError());
     static const bool dbg_locate = getenv("MM_LOCATE_DEBUG") != nullptr;
