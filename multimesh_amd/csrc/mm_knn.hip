@@ -680,7 +680,7 @@ static TreeParams tree_params_of(const mm_knn_tree *tr)
 // DEEPEST level the stack can lay out (sources in cells of 256 x the design density and more) --, (b) in the fused hex8
 // pipeline whenever the centroids ask for density levels at all.
 // Measured, round 4 (ms per pass; stack / tree; profiles/r04_graded_mesh_pipeline.json, r04_knn_graded_clouds.json): graded 10M
-// hex8 mesh u^1.5 12.5 / 10.4, u^2.2 47.8 / 37.1, uniform 3.43 / 6.7; random 4M clouds, k = 20: uniform 2.4 / 16.2, u^1.5 5.9 / 15.0,
+// hex8 mesh u^1.5 11.6 / 9.6, u^2.2 47.8 / 36.8, uniform 3.5 / 6.5; random 4M clouds, k = 20: uniform 2.4 / 16.2, u^1.5 5.9 / 15.0,
 // u^2 9.9 / 16.5, u^3 25.6 / 19.7; a 27 x refined region, k = 8: 3.4 / 4.9.  Read per call.
 static int tree_mode()
 {
